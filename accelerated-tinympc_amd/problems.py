@@ -1,0 +1,154 @@
+"""Problem classes and synthetic batch generators for the batched TinyMPC solver.
+
+Host-side product code (numpy only).  It mirrors the *inputs* of the reference's example
+programs so that the batched solver can be driven on the same problems:
+
+* quadrotor(rate, N)     — Crazyflie model + precomputed cache, numbers of
+                           /root/reference/examples/problem_data/quadrotor_{20,50,100}hz_params.hpp
+                           (re-encoded by tools/import_problem_data.py into data/*.json).
+* cartpole(N)            — model of examples/codegen_cartpole.cpp:22-28 (A, B column-major there),
+                           cache from the Riccati recursion of src/tinympc/codegen.cpp:254-292.
+* random_system(...)     — seeded marginally-stable synthetic system.
+* y_axis_line()          — the 301-point reference trajectory of
+                           examples/trajectory_data/quadrotor_20hz_y_axis_line.hpp (it is analytic).
+* hover_batch / tracking_batch — the synthetic batches of BASELINE.json configs 2 and 3.
+
+Matrices are numpy arrays in logical (row, col) indexing, float64; the solver casts to fp32.
+"""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+
+import numpy as np
+
+DATA = Path(__file__).resolve().parent / "data"
+
+NTOTAL = 301  # src/tinympc/glob_opts.hpp:9
+
+
+def _mat(entry):
+    vals = np.array([float(v) for v in entry["values"]], dtype=np.float64)
+    return vals.reshape(entry["shape"])  # row-major literals (quadrotor_20hz_params.hpp, Eigen::RowMajor maps)
+
+
+def quadrotor(rate: int = 20, N: int = 30) -> dict:
+    """Quadrotor problem of examples/quadrotor_hovering.cpp:33-47 (nx=12, nu=4)."""
+    d = json.loads((DATA / f"quadrotor_{rate}hz.json").read_text())
+    prob = dict(name=f"quadrotor_{rate}hz", nx=d["nx"], nu=d["nu"], N=N, rho=float(d["rho"]))
+    for k in ("Adyn", "Bdyn", "Kinf", "Pinf", "Quu_inv", "AmBKt", "Q", "R"):
+        prob[k] = _mat(d[k])
+    # constant box bounds of quadrotor_hovering.cpp:44-47
+    prob["u_min"], prob["u_max"], prob["x_min"], prob["x_max"] = -0.5, 0.5, -5.0, 5.0
+    return prob
+
+
+def cartpole(N: int = 10, riccati=None) -> dict:
+    """Cartpole of examples/codegen_cartpole.cpp:17-28,51-60 (nx=4, nu=1, rho=0.1, bounds +-5).
+
+    `riccati(nx, nu, A, B, Q, R, rho) -> dict` supplies the cache; default is the product's own
+    host routine (accelerated-tinympc_amd/csrc/riccati.cpp through the C-ABI).
+    """
+    nx, nu = 4, 1
+    a_cm = [1.0, 0.0, 0.0, 0.0, 0.01, 1.0, 0.0, 0.0, 2.2330083403300767e-5, 0.004466210576510177,
+            1.0002605176397052, 0.05210579005928538, 7.443037974683548e-8, 2.2330083403300767e-5,
+            0.01000086835443038, 1.0002605176397052]
+    b_cm = [7.468368562730335e-5, 0.014936765390161838, 3.79763323185387e-5, 0.007595596218554721]
+    A = np.array(a_cm).reshape(nx, nx).T  # literals are column-major
+    B = np.array(b_cm).reshape(nu, nx).T
+    prob = dict(name="cartpole", nx=nx, nu=nu, N=N, rho=0.1, Adyn=A, Bdyn=B,
+                Q=np.array([10.0, 1.0, 10.0, 1.0]), R=np.array([1.0]),
+                u_min=-5.0, u_max=5.0, x_min=-5.0, x_max=5.0)
+    return with_cache(prob, riccati)
+
+
+def random_system(nx: int = 32, nu: int = 16, N: int = 50, seed: int = 1234, riccati=None) -> dict:
+    """Seeded marginally-stable random LTI system.
+
+    A = I + 0.05*G/sqrt(nx) rescaled to spectral radius 1 (avoids denormal-dominated decay),
+    B = 0.1*G', Q_i = 10, R_i = 1, rho = 1, bounds u in [-0.5,0.5], x in [-5,5].
+    """
+    rng = np.random.default_rng(seed)
+    A = np.eye(nx) + 0.05 * rng.standard_normal((nx, nx)) / np.sqrt(nx)
+    A = A / np.max(np.abs(np.linalg.eigvals(A)))
+    B = 0.1 * rng.standard_normal((nx, nu))
+    prob = dict(name=f"random_{nx}_{nu}", nx=nx, nu=nu, N=N, rho=1.0, Adyn=A, Bdyn=B,
+                Q=np.full(nx, 10.0), R=np.full(nu, 1.0), u_min=-0.5, u_max=0.5, x_min=-5.0, x_max=5.0)
+    return with_cache(prob, riccati)
+
+
+def with_cache(prob: dict, riccati=None) -> dict:
+    """Attach Kinf/Pinf/Quu_inv/AmBKt computed by the Riccati recursion (codegen.cpp:254-292).
+
+    NOTE the reference's codegen stores Q+rho in work.Q (codegen.cpp:255,:433) whereas the
+    shipped quadrotor headers store the raw Q; `tiny_solve` just uses whatever is in work.Q
+    (admm.cpp:81).  We follow the codegen convention here: prob["Q"] becomes Q+rho.
+    """
+    if riccati is None:
+        from . import riccati as _r
+        riccati = _r
+    cache = riccati(prob["nx"], prob["nu"], prob["Adyn"], prob["Bdyn"], prob["Q"], prob["R"], prob["rho"])
+    if isinstance(cache, tuple):
+        cache = cache[0]
+    out = dict(prob)
+    out.update({k: np.asarray(cache[k], np.float64) for k in ("Kinf", "Pinf", "Quu_inv", "AmBKt")})
+    out["Q_raw"] = np.asarray(prob["Q"], np.float64)
+    out["Q"] = out["Q_raw"] + prob["rho"]
+    return out
+
+
+def y_axis_line() -> np.ndarray:
+    """(301, 12) reference trajectory: z = 1 m, y from 0 to 4 m, dy = 0.2666667 m/s (0 in the last row).
+
+    The reference stores it as 7-decimal literals (quadrotor_20hz_y_axis_line.hpp:6-306); we
+    regenerate the same decimals analytically (tests/test_problems.py checks equality against the
+    header when the reference tree is present).
+    """
+    X = np.zeros((NTOTAL, 12))
+    for k in range(NTOTAL):
+        X[k, 1] = float(f"{k * 4.0 / 300.0:.7f}")
+        X[k, 2] = 1.0
+        X[k, 7] = 0.2666667 if k < NTOTAL - 1 else 0.0
+    return X
+
+
+HOVER_X0 = np.array([0, 1, 0, 0.2, 0, 0, 0.1, 0, 0, 0, 0, 0], dtype=np.float64)   # quadrotor_hovering.cpp:88
+HOVER_XREF = np.array([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0], dtype=np.float64)    # quadrotor_hovering.cpp:83-85
+
+
+def hover_batch(B: int, N: int = 30, seed: int = 20241024, spread: float = 0.2):
+    """BASELINE.json config 2: x0_b = x0_nom + U(-spread, spread)^12; Xref = hover set-point, shared.
+
+    Returns (x0 (B,12) float32, Xref (N,12) float32).
+    """
+    rng = np.random.default_rng(seed)
+    x0 = HOVER_X0[None, :] + rng.uniform(-spread, spread, size=(B, 12))
+    xref = np.tile(HOVER_XREF, (N, 1))
+    return x0.astype(np.float32), xref.astype(np.float32)
+
+
+def tracking_batch(B: int, N: int = 30, seed: int = 20241024, spread: float = 0.05):
+    """BASELINE.json config 3: instance b tracks the window of y_axis_line starting at
+    k_b = b mod (301 - N) (quadrotor_tracking.cpp:84-85,101), x0_b = Xref_b[0] + U(-spread, spread)^12.
+
+    Returns (x0 (B,12) float32, table (301,12) float32, start (B,) int32).  The per-instance
+    reference is Xref_b = table[start[b] : start[b]+N].
+    """
+    rng = np.random.default_rng(seed)
+    table = y_axis_line()
+    start = (np.arange(B) % (NTOTAL - N)).astype(np.int32)
+    x0 = table[start] + rng.uniform(-spread, spread, size=(B, 12))
+    return x0.astype(np.float32), table.astype(np.float32), start
+
+
+def expand_windows(table: np.ndarray, start: np.ndarray, N: int) -> np.ndarray:
+    """Materialise per-instance references (B, N, nx) from a trajectory table and window starts."""
+    idx = start[:, None].astype(np.int64) + np.arange(N)[None, :]
+    return np.ascontiguousarray(table[idx])
+
+
+def bounds_arrays(prob: dict, dtype=np.float32):
+    """Constant box bounds as shared (N, nx) / (N-1, nu) arrays (quadrotor_hovering.cpp:44-47)."""
+    N, nx, nu = prob["N"], prob["nx"], prob["nu"]
+    return (np.full((N, nx), prob["x_min"], dtype), np.full((N, nx), prob["x_max"], dtype),
+            np.full((N - 1, nu), prob["u_min"], dtype), np.full((N - 1, nu), prob["u_max"], dtype))

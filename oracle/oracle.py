@@ -1,0 +1,238 @@
+"""TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+
+ctypes bindings for (a) our CPU restatement of the TinyMPC ADMM hot path
+(oracle/tinympc_oracle.c, restating /root/reference/src/tinympc/admm.cpp:15-152 and
+codegen.cpp:254-292) and (b) the compiled reference itself (oracle/_ref/*.so, built by
+oracle/Makefile from the reference sources where they lie; present only where it was
+built, i.e. in the build container and — as a prebuilt, git-ignored binary — on the GPU box).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+
+Array convention (host-visible layout of the batched API): state-type arrays are
+(B, N, nx) float arrays, input-type arrays are (B, N-1, nu): instance-major, then horizon
+step, then state index — i.e. each instance is the reference's column-major nx x N matrix.
+Matrices (Kinf, Adyn, ...) are passed as 2-D numpy arrays in logical (row, col) indexing and
+flattened column-major internally (Eigen's storage order, types.hpp:13-21).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+STATE_X = ("x", "q", "p", "v", "vnew", "g")       # (B, N, nx)
+STATE_U = ("u", "r", "d", "z", "znew", "y")       # (B, N-1, nu)
+STATE_ORDER = ("x", "u", "q", "r", "p", "d", "v", "vnew", "z", "znew", "g", "y")
+
+
+def build(ref: bool = True) -> None:
+    """Compile the oracle (and, when /root/reference exists, oracle/_ref)."""
+    target = "all" if ref else "liboracle"
+    subprocess.run(["make", "-s", "-C", str(HERE), target], check=True)
+
+
+def _lib():
+    p = HERE / "libtinympc_oracle.so"
+    if not p.exists():
+        build(ref=False)
+    return C.CDLL(str(p))
+
+
+def _colmajor(a, dt):
+    return np.ascontiguousarray(np.asarray(a, dtype=dt).T).ravel()  # column-major flat copy
+
+
+def _ptr(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+class _Dtype:
+    def __init__(self, dt):
+        self.np = np.dtype(dt)
+        self.ct = C.c_float if self.np == np.float32 else C.c_double
+        self.suf = "f32" if self.np == np.float32 else "f64"
+
+
+def _problem_struct(T):
+    class OracleProblem(C.Structure):
+        _fields_ = [("nx", C.c_int), ("nu", C.c_int), ("N", C.c_int), ("rho", T.ct),
+                    ("Kinf", C.POINTER(T.ct)), ("Pinf", C.POINTER(T.ct)), ("Quu_inv", C.POINTER(T.ct)),
+                    ("AmBKt", C.POINTER(T.ct)), ("Adyn", C.POINTER(T.ct)), ("Bdyn", C.POINTER(T.ct)),
+                    ("Q", C.POINTER(T.ct)), ("abs_pri_tol", T.ct), ("abs_dua_tol", T.ct),
+                    ("max_iter", C.c_int), ("check_termination", C.c_int),
+                    ("en_state_bound", C.c_int), ("en_input_bound", C.c_int)]
+    return OracleProblem
+
+
+def _batch_struct(T):
+    P = C.POINTER(T.ct)
+
+    class OracleBatch(C.Structure):
+        _fields_ = ([("batch", C.c_int)] + [(n, P) for n in STATE_ORDER] +
+                    [(n, P) for n in ("u_min", "u_max", "x_min", "x_max", "Xref")] +
+                    [("bound_stride_x", C.c_longlong), ("bound_stride_u", C.c_longlong),
+                     ("xref_stride", C.c_longlong), ("residuals", P),
+                     ("status", C.POINTER(C.c_int)), ("iter", C.POINTER(C.c_int))])
+    return OracleBatch
+
+
+DEFAULT_SETTINGS = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1,
+                        en_state_bound=1, en_input_bound=1)  # examples/quadrotor_hovering.cpp:73-78
+
+
+def new_state(B, nx, nu, N, dtype=np.float32):
+    """All-zero workspace (what the reference examples start from, quadrotor_hovering.cpp:52-71)."""
+    st = {k: np.zeros((B, N, nx), dtype) for k in STATE_X}
+    st.update({k: np.zeros((B, N - 1, nu), dtype) for k in STATE_U})
+    st["residuals"] = np.zeros((B, 4), dtype)
+    st["status"] = np.zeros(B, np.int32)
+    st["iter"] = np.zeros(B, np.int32)
+    return st
+
+
+def copy_state(st):
+    return {k: v.copy() for k, v in st.items()}
+
+
+def _bcast(a, B, shape, dt):
+    """Return (contiguous array, per-instance stride in elements; 0 = shared)."""
+    a = np.ascontiguousarray(np.asarray(a, dtype=dt))
+    n = int(np.prod(shape))
+    if a.size == n:
+        return a.reshape(shape), 0
+    assert a.size == B * n, (a.shape, B, shape)
+    return a.reshape((B,) + tuple(shape)), n
+
+
+class _Solver:
+    """Common driver for the oracle and for a compiled-reference library."""
+
+    def __init__(self, prob, dtype=np.float32, settings=None):
+        self.T = _Dtype(dtype)
+        self.prob = prob
+        self.nx, self.nu, self.N = prob["nx"], prob["nu"], prob["N"]
+        self.settings = dict(DEFAULT_SETTINGS)
+        if settings:
+            self.settings.update(settings)
+        dt = self.T.np
+        self._m = {k: _colmajor(prob[k], dt) for k in ("Kinf", "Pinf", "Quu_inv", "AmBKt", "Adyn", "Bdyn")}
+        self._m["Q"] = np.ascontiguousarray(np.asarray(prob["Q"], dt).ravel())
+        self.rho = dt.type(prob["rho"])
+
+    def _prep(self, st, x_min, x_max, u_min, u_max, Xref):
+        dt = self.T.np
+        B = st["x"].shape[0]
+        for k in STATE_ORDER + ("residuals",):
+            assert st[k].dtype == dt and st[k].flags.c_contiguous, k
+        xmn, sx1 = _bcast(x_min, B, (self.N, self.nx), dt)
+        xmx, sx2 = _bcast(x_max, B, (self.N, self.nx), dt)
+        umn, su1 = _bcast(u_min, B, (self.N - 1, self.nu), dt)
+        umx, su2 = _bcast(u_max, B, (self.N - 1, self.nu), dt)
+        xr, sr = _bcast(Xref, B, (self.N, self.nx), dt)
+        assert sx1 == sx2 and su1 == su2
+        return B, (umn, umx, xmn, xmx, xr), (sx1, su1, sr)
+
+
+class Oracle(_Solver):
+    """Our CPU restatement (oracle/tinympc_oracle.c)."""
+
+    kind = "port"
+
+    def __init__(self, prob, dtype=np.float32, settings=None):
+        super().__init__(prob, dtype, settings)
+        self.lib = _lib()
+        self.PS = _problem_struct(self.T)
+        self.BS = _batch_struct(self.T)
+        self.fn = getattr(self.lib, f"oracle_solve_batch_{self.T.suf}")
+        self.fn.restype = C.c_int
+        self.fn.argtypes = [C.POINTER(self.PS), C.POINTER(self.BS), C.c_int]
+
+    def _pstruct(self):
+        s = self.settings
+        ct = self.T.ct
+        return self.PS(self.nx, self.nu, self.N, self.rho, *[_ptr(self._m[k], ct) for k in
+                       ("Kinf", "Pinf", "Quu_inv", "AmBKt", "Adyn", "Bdyn", "Q")],
+                       s["abs_pri_tol"], s["abs_dua_tol"], s["max_iter"], s["check_termination"],
+                       s["en_state_bound"], s["en_input_bound"])
+
+    def solve(self, st, x_min, x_max, u_min, u_max, Xref, nthreads=1, ftz=False):
+        """One tiny_solve() per instance, in place on `st`.  Returns #instances that hit max_iter."""
+        B, ins, (sx, su, sr) = self._prep(st, x_min, x_max, u_min, u_max, Xref)
+        ct = self.T.ct
+        self.lib.oracle_set_ftz_daz(1 if ftz else 0)
+        bs = self.BS(B, *[_ptr(st[k], ct) for k in STATE_ORDER], *[_ptr(a, ct) for a in ins],
+                     sx, su, sr, _ptr(st["residuals"], ct), _ptr(st["status"], C.c_int), _ptr(st["iter"], C.c_int))
+        ps = self._pstruct()
+        rc = self.fn(C.byref(ps), C.byref(bs), int(nthreads))
+        self.lib.oracle_set_ftz_daz(0)
+        return rc
+
+
+def ref_lib_path(dtype, nx, nu, N):
+    suf = "f32" if np.dtype(dtype) == np.float32 else "f64"
+    return HERE / "_ref" / f"libtinympc_ref_{suf}_{nx}_{nu}_{N}.so"
+
+
+def have_ref(dtype, nx, nu, N):
+    return ref_lib_path(dtype, nx, nu, N).exists()
+
+
+class Reference(_Solver):
+    """The compiled reference (Eigen, src/tinympc/admm.cpp) behind oracle/ref_shim.cpp."""
+
+    kind = "reference"
+
+    def __init__(self, prob, dtype=np.float32, settings=None):
+        super().__init__(prob, dtype, settings)
+        path = ref_lib_path(dtype, self.nx, self.nu, self.N)
+        if not path.exists():
+            raise FileNotFoundError(f"{path} (build it with `make -C oracle ref` where /root/reference exists)")
+        self.lib = C.CDLL(str(path))
+        d = (C.c_int * 4)()
+        self.lib.ref_dims(C.byref(d, 0), C.byref(d, 4), C.byref(d, 8), C.byref(d, 12))
+        assert (d[0], d[1], d[2]) == (self.nx, self.nu, self.N) and bool(d[3]) == (self.T.suf == "f64")
+        ct, P = self.T.ct, C.POINTER(self.T.ct)
+        self.lib.ref_set_problem.argtypes = [ct] + [P] * 7
+        self.lib.ref_set_problem.restype = None
+        self.lib.ref_set_settings.argtypes = [ct, ct, C.c_int, C.c_int, C.c_int, C.c_int]
+        self.lib.ref_set_settings.restype = None
+        self.lib.ref_solve_batch.argtypes = ([C.c_int] + [P] * 17 + [C.c_longlong] * 3 +
+                                             [P, C.POINTER(C.c_int), C.POINTER(C.c_int)])
+        self.lib.ref_solve_batch.restype = C.c_int
+
+    def solve(self, st, x_min, x_max, u_min, u_max, Xref, nthreads=1, ftz=False):
+        assert nthreads == 1, "the reference is single-threaded (one global solver, tiny_wrapper.cpp)"
+        B, ins, (sx, su, sr) = self._prep(st, x_min, x_max, u_min, u_max, Xref)
+        ct = self.T.ct
+        s = self.settings
+        self.lib.ref_set_problem(self.rho, *[_ptr(self._m[k], ct) for k in
+                                 ("Kinf", "Pinf", "Quu_inv", "AmBKt", "Adyn", "Bdyn", "Q")])
+        self.lib.ref_set_settings(s["abs_pri_tol"], s["abs_dua_tol"], s["max_iter"], s["check_termination"],
+                                  s["en_state_bound"], s["en_input_bound"])
+        return self.lib.ref_solve_batch(B, *[_ptr(st[k], ct) for k in STATE_ORDER], *[_ptr(a, ct) for a in ins],
+                                        sx, su, sr, _ptr(st["residuals"], ct), _ptr(st["status"], C.c_int),
+                                        _ptr(st["iter"], C.c_int))
+
+
+def riccati(nx, nu, A, B, Q, R, rho):
+    """fp64 Riccati cache precompute, restating codegen.cpp:254-292.  Returns dict + iteration count."""
+    lib = _lib()
+    P = C.POINTER(C.c_double)
+    lib.oracle_riccati_f64.argtypes = [C.c_int, C.c_int, P, P, P, P, C.c_double, P, P, P, P, P]
+    lib.oracle_riccati_f64.restype = C.c_int
+    a, b = _colmajor(A, np.float64), _colmajor(B, np.float64)
+    q, r = np.ascontiguousarray(Q, np.float64).ravel(), np.ascontiguousarray(R, np.float64).ravel()
+    K, Pm, Qi, Am, cd = (np.zeros(nu * nx), np.zeros(nx * nx), np.zeros(nu * nu), np.zeros(nx * nx),
+                         np.zeros(nx * nu))
+    it = lib.oracle_riccati_f64(nx, nu, _ptr(a, C.c_double), _ptr(b, C.c_double), _ptr(q, C.c_double),
+                                _ptr(r, C.c_double), float(rho), _ptr(K, C.c_double), _ptr(Pm, C.c_double),
+                                _ptr(Qi, C.c_double), _ptr(Am, C.c_double), _ptr(cd, C.c_double))
+    if it < 0:
+        raise RuntimeError(f"oracle_riccati failed rc={it}")
+    return dict(Kinf=K.reshape(nx, nu).T.copy(), Pinf=Pm.reshape(nx, nx).T.copy(),
+                Quu_inv=Qi.reshape(nu, nu).T.copy(), AmBKt=Am.reshape(nx, nx).T.copy(),
+                coeff_d2p=cd.reshape(nu, nx).T.copy()), it
