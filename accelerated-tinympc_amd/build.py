@@ -1,0 +1,60 @@
+"""Build the HIP shared library (gfx950 only) in-tree.
+
+    python accelerated-tinympc_amd/build.py [--force]
+
+Produces accelerated-tinympc_amd/lib/libtinympc_hip.so with `hipcc --offload-arch=gfx950`.
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the tree.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIB = PKG / "lib" / "libtinympc_hip.so"
+SOURCES = ["tinympc_batch.hip", "admm_stream.hip", "admm_resident.hip", "riccati.cpp"]
+HEADERS = [CSRC / "tinympc_internal.h", PKG.parent / "include" / "tinympc_batch.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-gpu-rdc"]
+
+
+def _objs():
+    return [(CSRC / s, PKG / "lib" / (Path(s).stem + ".o")) for s in SOURCES if (CSRC / s).exists()]
+
+
+def needs_build() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = [s for s, _ in _objs()] + HEADERS + [Path(__file__)]
+    return any(d.stat().st_mtime > t for d in deps if d.exists())
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    LIB.parent.mkdir(parents=True, exist_ok=True)
+    hdr_t = max(h.stat().st_mtime for h in HEADERS + [Path(__file__)] if h.exists())
+    procs = []
+    for src, obj in _objs():
+        if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_t):
+            continue
+        cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for _, o in _objs()]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,78 @@
+// Internal definitions shared by the HIP kernels and the C-ABI host code.
+// gfx950 (MI355X / CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace tinympc
+{
+
+// One wavefront solves TILE = 16 instances: they are the 16 columns of the
+// v_mfma_f32_16x16x4_f32 tile, so every gain x state mat-vec of the horizon sweeps is a
+// handful of MFMA issues whose A operand (a slice of the gain matrix) sits in ONE VGPR.
+//
+// Device-internal ("tile") layout of every per-instance array
+//   x-family (x,q,p,v,vnew,g,Xref,x_min,x_max):  float [ntiles][N  ][64 lanes][NXC]
+//   u-family (u,r,d,z,znew,y,u_min,u_max):       float [ntiles][N-1][64 lanes][NUC]
+// lane = 16*gq + c holds, for instance 16*tile + c, the rows {4*ch + gq : ch < NXC} of the
+// vector: "chunk" ch = four consecutive rows, one per lane group gq.  That is exactly the
+// B-operand layout of the MFMA (lane (gq,c) supplies B[k=gq][col=c]) for the K-slice ch, and
+// (with the gain matrices' rows permuted on the host) also its D layout, so a sweep never
+// moves data between lanes.  NXC = ceil(nx/4), NUC = ceil(nu/4); padded rows are zero.
+constexpr int TILE = 16;
+constexpr int WAVE = 64;
+constexpr int TINY_STATUS_SOLVED_ = 1;    // work->status, admm.cpp:136
+constexpr int TINY_STATUS_UNSOLVED_ = 11; // admm.cpp:114
+
+// (NXC, NUC) pairs with compiled kernels: quadrotor (12,4), cartpole (4,1), random (32,16), test dims (8,3)
+#define TINY_FOR_EACH_DIMS(X) X(3, 1) X(1, 1) X(8, 4) X(2, 1)
+
+template <int NXC_, int NUC_>
+struct Dims
+{
+    static constexpr int NXC = NXC_;                  // x chunks
+    static constexpr int NUC = NUC_;                  // u chunks
+    static constexpr int NCH = NXC_ + NUC_;           // stacked [x;u] chunks
+    static constexpr int NT = (NCH + 3) / 4;          // 16-row output tiles over the stacked vector
+    static constexpr int NTX = (NXC_ + 3) / 4;        // tiles 0..NTX-1 contain x chunks
+    static constexpr int TU0 = NXC_ / 4;              // first tile that contains a u chunk
+    static constexpr int NTU = NT - TU0;              // tiles TU0..NT-1 contain u chunks
+    // MFMA A-operand registers (one VGPR each), in the order they are packed by the host:
+    static constexpr int N_A1 = NT * NXC_;            // fwd  [A;-K] * x
+    static constexpr int N_A2 = NTX * NUC_;           // fwd  [B]    * u
+    static constexpr int N_A3 = NT * NXC_;            // bwd  [AmBKt; B^T] * p
+    static constexpr int N_A4 = NTX * NUC_;           // bwd  [-K^T] * r
+    static constexpr int N_A5 = NTU * NUC_;           // bwd  [Quu_inv] * (B^T p + r)
+    static constexpr int N_AP = NTX * NXC_;           // terminal [-Pinf^T] * Xref_{N-1}
+    static constexpr int N_OPND = N_A1 + N_A2 + N_A3 + N_A4 + N_A5 + N_AP;
+};
+
+struct SolveParams
+{
+    int nx, nu, N, batch, ntiles;
+    float rho, abs_pri_tol, abs_dua_tol;
+    int max_iter, check_termination, en_state_bound, en_input_bound;
+    int duals_zero; // y = g = 0 on entry (reset_dual_variables() folded into the solve)
+    int cold_start; // d = v = z = y = g = 0 on entry (reset_workspace() folded into the solve)
+    int xref_mode;  // 0: tile array (per-instance or shared), 1: window gather from a trajectory table
+    float *x, *q, *p, *v, *vnew, *g;      // x-family
+    float *u, *r, *d, *z, *znew, *y;      // u-family
+    const float *xmin, *xmax, *umin, *umax, *xref;
+    long long xb_tile_stride, ub_tile_stride, xref_tile_stride; // floats between tiles; 0 = shared by the batch
+    const float *xref_table; // [rows][4 gq][NXC]
+    const int *xref_start;   // [batch]
+    int table_rows;
+    float *res;  // [batch][4]
+    int *status; // [batch]
+    int *iter;   // [batch]
+    int *n_unsolved;
+    const float *opnd; // [N_OPND][64]
+    const float *qvec; // [64][NXC]  Q(row) per lane
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+hipError_t launch_admm_stream(int nxc, int nuc, const SolveParams &P, hipStream_t stream);
+
+} // namespace tinympc

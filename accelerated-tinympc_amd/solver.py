@@ -1,0 +1,277 @@
+"""ctypes host mirror of the C-ABI (include/tinympc_batch.h).
+
+`TinyBatchSolver` keeps the names and call sequence of the reference's foreign-language
+wrapper (src/tinympc/tiny_wrapper.hpp:14-23: set_x0, set_xref, set_umin/umax, set_xmin/xmax,
+reset_dual_variables, call_tiny_solve, get_x, get_u), batched: every array gains a leading
+instance axis.  All compute happens in the HIP library; there is no CPU fallback — a missing
+library or a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from . import build as _build
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "lib" / "libtinympc_hip.so"
+
+ARRAY_IDS = {"x": 0, "u": 1, "q": 2, "r": 3, "p": 4, "d": 5, "v": 6, "vnew": 7, "z": 8, "znew": 9, "g": 10, "y": 11}
+X_FAMILY = ("x", "q", "p", "v", "vnew", "g")
+TINY_SOLVED, TINY_UNSOLVED = 1, 11
+
+_lib = None
+
+
+class TinyBatchError(RuntimeError):
+    pass
+
+
+def load_library(build_if_missing: bool = False) -> C.CDLL:
+    """dlopen the in-tree HIP library and declare its prototypes.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        if build_if_missing:
+            _build.build()
+        else:
+            raise TinyBatchError(f"{LIB_PATH} is missing: run `python accelerated-tinympc_amd/build.py` "
+                                 "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(str(LIB_PATH))
+    F, I, P = C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p
+    D = C.POINTER(C.c_double)
+    sig = {
+        "tiny_batch_create": [C.POINTER(P), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
+        "tiny_batch_set_stream": [P, P],
+        "tiny_batch_synchronize": [P],
+        "tiny_batch_set_cache": [P, C.c_float, F, F, F, F],
+        "tiny_batch_set_dynamics": [P, F, F, F],
+        "tiny_batch_set_settings": [P, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int],
+        "tiny_batch_set_x0": [P, F],
+        "tiny_batch_set_xref": [P, F, C.c_int],
+        "tiny_batch_set_xref_window": [P, F, C.c_int, I],
+        "tiny_batch_set_umin": [P, F, C.c_int], "tiny_batch_set_umax": [P, F, C.c_int],
+        "tiny_batch_set_xmin": [P, F, C.c_int], "tiny_batch_set_xmax": [P, F, C.c_int],
+        "tiny_batch_reset_dual_variables": [P],
+        "tiny_batch_solve": [P], "tiny_batch_solve_async": [P], "tiny_batch_wait": [P, I],
+        "tiny_batch_get_x": [P, F], "tiny_batch_get_u": [P, F],
+        "tiny_batch_get_status": [P, I, I, F], "tiny_batch_set_status": [P, I, I, F],
+        "tiny_batch_set_array": [P, C.c_int, F], "tiny_batch_get_array": [P, C.c_int, F],
+        "tiny_batch_reset_workspace": [P],
+        "tiny_batch_set_x0_device": [P, P], "tiny_batch_get_u0_device": [P, P],
+        "tiny_batch_mpc_step_async": [P, C.c_int], "tiny_batch_get_x0": [P, F],
+        "tiny_batch_enable_timing": [P, C.c_int], "tiny_batch_last_solve_ms": [P, F],
+        "tiny_batch_select_kernel": [P, C.c_int],
+        "tiny_riccati": [C.c_int, C.c_int, D, D, D, D, C.c_double, D, D, D, D, D, I],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = args, C.c_int
+    lib.tiny_batch_destroy.argtypes, lib.tiny_batch_destroy.restype = [P], None
+    lib.tiny_batch_last_error.argtypes, lib.tiny_batch_last_error.restype = [], C.c_char_p
+    lib.tiny_batch_kernel_name.argtypes, lib.tiny_batch_kernel_name.restype = [P], C.c_char_p
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    """Names declared in include/tinympc_batch.h (used by the CPU-side ABI test)."""
+    import re
+    txt = (PKG.parent / "include" / "tinympc_batch.h").read_text()
+    return sorted(set(re.findall(r"\b(tiny_(?:batch_[a-z0-9_]+|riccati))\s*\(", txt)))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _colmajor(m):
+    return np.ascontiguousarray(np.asarray(m, dtype=np.float32).T).ravel()
+
+
+def riccati(nx, nu, A, B, Q, R, rho):
+    """Host fp64 cache precompute (csrc/riccati.cpp; restates codegen.cpp:254-292)."""
+    lib = load_library()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    a = np.ascontiguousarray(np.asarray(A, np.float64).T).ravel()
+    b = np.ascontiguousarray(np.asarray(B, np.float64).T).ravel()
+    q = np.ascontiguousarray(Q, np.float64).ravel()
+    r = np.ascontiguousarray(R, np.float64).ravel()
+    K, Pm, Qi, Am, cd = (np.zeros(nu * nx), np.zeros(nx * nx), np.zeros(nu * nu), np.zeros(nx * nx), np.zeros(nx * nu))
+    it = C.c_int(0)
+    rc = lib.tiny_riccati(nx, nu, dp(a), dp(b), dp(q), dp(r), float(rho), dp(K), dp(Pm), dp(Qi), dp(Am), dp(cd), C.byref(it))
+    if rc != 0:
+        raise TinyBatchError(f"tiny_riccati failed rc={rc}")
+    return dict(Kinf=K.reshape(nx, nu).T.copy(), Pinf=Pm.reshape(nx, nx).T.copy(), Quu_inv=Qi.reshape(nu, nu).T.copy(),
+                AmBKt=Am.reshape(nx, nx).T.copy(), coeff_d2p=cd.reshape(nu, nx).T.copy(), iters=it.value)
+
+
+class TinyBatchSolver:
+    """Device-resident batch of TinyMPC problem instances of one class (nx, nu, N)."""
+
+    def __init__(self, prob: dict, batch: int, device: int = 0, settings: dict | None = None):
+        self.lib = load_library()
+        self.nx, self.nu, self.N, self.B = int(prob["nx"]), int(prob["nu"]), int(prob["N"]), int(batch)
+        self._h = C.c_void_p()
+        self._check(self.lib.tiny_batch_create(C.byref(self._h), self.nx, self.nu, self.N, self.B, int(device)))
+        k, p, qi, am = (_colmajor(prob[n]) for n in ("Kinf", "Pinf", "Quu_inv", "AmBKt"))
+        self._check(self.lib.tiny_batch_set_cache(self._h, float(prob["rho"]), _fp(k), _fp(p), _fp(qi), _fp(am)))
+        a, b, q = _colmajor(prob["Adyn"]), _colmajor(prob["Bdyn"]), _f32(np.asarray(prob["Q"]).ravel())
+        self._check(self.lib.tiny_batch_set_dynamics(self._h, _fp(a), _fp(b), _fp(q)))
+        s = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1, en_state_bound=1,
+                 en_input_bound=1)  # examples/quadrotor_hovering.cpp:73-78
+        if settings:
+            s.update(settings)
+        self.set_settings(**s)
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc < 0:
+            raise TinyBatchError(f"rc={rc}: {self.lib.tiny_batch_last_error().decode()}")
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.tiny_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _xshape(self, name):
+        return (self.B, self.N, self.nx) if name in X_FAMILY else (self.B, self.N - 1, self.nu)
+
+    # -- TinySettings -----------------------------------------------------------------------
+    def set_settings(self, abs_pri_tol, abs_dua_tol, max_iter, check_termination, en_state_bound, en_input_bound):
+        self.settings = dict(abs_pri_tol=abs_pri_tol, abs_dua_tol=abs_dua_tol, max_iter=max_iter,
+                             check_termination=check_termination, en_state_bound=en_state_bound,
+                             en_input_bound=en_input_bound)
+        self._check(self.lib.tiny_batch_set_settings(self._h, abs_pri_tol, abs_dua_tol, max_iter, check_termination,
+                                                     en_state_bound, en_input_bound))
+
+    # -- wrapper twins (tiny_wrapper.hpp:14-23) ------------------------------------------------
+    def set_x0(self, x0):
+        a = _f32(x0); assert a.shape == (self.B, self.nx), a.shape
+        self._check(self.lib.tiny_batch_set_x0(self._h, _fp(a)))
+
+    def _set_steps(self, fn, arr, steps, dim):
+        a = _f32(arr)
+        if a.shape == (steps, dim):
+            shared = 1
+        else:
+            assert a.shape == (self.B, steps, dim), (a.shape, (self.B, steps, dim))
+            shared = 0
+        self._check(fn(self._h, _fp(a), shared))
+
+    def set_xref(self, xref):
+        self._set_steps(self.lib.tiny_batch_set_xref, xref, self.N, self.nx)
+
+    def set_xref_window(self, table, start):
+        t = _f32(table); s = np.ascontiguousarray(start, dtype=np.int32)
+        assert t.ndim == 2 and t.shape[1] == self.nx and s.shape == (self.B,)
+        self._check(self.lib.tiny_batch_set_xref_window(self._h, _fp(t), t.shape[0], s.ctypes.data_as(C.POINTER(C.c_int))))
+
+    def set_umin(self, a): self._set_steps(self.lib.tiny_batch_set_umin, a, self.N - 1, self.nu)
+    def set_umax(self, a): self._set_steps(self.lib.tiny_batch_set_umax, a, self.N - 1, self.nu)
+    def set_xmin(self, a): self._set_steps(self.lib.tiny_batch_set_xmin, a, self.N, self.nx)
+    def set_xmax(self, a): self._set_steps(self.lib.tiny_batch_set_xmax, a, self.N, self.nx)
+
+    def set_bounds(self, x_min, x_max, u_min, u_max):
+        self.set_xmin(x_min); self.set_xmax(x_max); self.set_umin(u_min); self.set_umax(u_max)
+
+    def reset_dual_variables(self):
+        self._check(self.lib.tiny_batch_reset_dual_variables(self._h))
+
+    def solve(self) -> int:
+        """call_tiny_solve for every instance; 0 = all converged, 1 = some hit max_iter."""
+        return self._check(self.lib.tiny_batch_solve(self._h))
+
+    call_tiny_solve = solve
+
+    def solve_async(self):
+        self._check(self.lib.tiny_batch_solve_async(self._h))
+
+    def wait(self) -> int:
+        n = C.c_int(0)
+        self._check(self.lib.tiny_batch_wait(self._h, C.byref(n)))
+        return n.value
+
+    def get_x(self): return self.get_array("x")
+    def get_u(self): return self.get_array("u")
+
+    def get_status(self):
+        it = np.zeros(self.B, np.int32); st = np.zeros(self.B, np.int32); res = np.zeros((self.B, 4), np.float32)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+        self._check(self.lib.tiny_batch_get_status(self._h, ip(it), ip(st), _fp(res)))
+        return it, st, res
+
+    def set_status(self, iter=None, status=None, residuals=None):
+        ip = lambda a: None if a is None else np.ascontiguousarray(a, np.int32).ctypes.data_as(C.POINTER(C.c_int))
+        keep = [None if a is None else np.ascontiguousarray(a, np.int32) for a in (iter, status)]
+        r = None if residuals is None else _f32(residuals)
+        self._check(self.lib.tiny_batch_set_status(
+            self._h, None if keep[0] is None else keep[0].ctypes.data_as(C.POINTER(C.c_int)),
+            None if keep[1] is None else keep[1].ctypes.data_as(C.POINTER(C.c_int)), None if r is None else _fp(r)))
+
+    # -- whole workspace ------------------------------------------------------------------------
+    def get_array(self, name):
+        out = np.empty(self._xshape(name), np.float32)
+        self._check(self.lib.tiny_batch_get_array(self._h, ARRAY_IDS[name], _fp(out)))
+        return out
+
+    def set_array(self, name, arr):
+        a = _f32(arr); assert a.shape == self._xshape(name), (name, a.shape)
+        self._check(self.lib.tiny_batch_set_array(self._h, ARRAY_IDS[name], _fp(a)))
+
+    def get_state(self) -> dict:
+        st = {k: self.get_array(k) for k in ARRAY_IDS}
+        st["iter"], st["status"], st["residuals"] = self.get_status()
+        return st
+
+    def set_state(self, st: dict):
+        for k in ARRAY_IDS:
+            if k in st:
+                self.set_array(k, st[k])
+        self.set_status(st.get("iter"), st.get("status"), st.get("residuals"))
+
+    def reset_workspace(self):
+        self._check(self.lib.tiny_batch_reset_workspace(self._h))
+
+    # -- closed loop / measurement ------------------------------------------------------------
+    def mpc_step_async(self, window_advance: int = 0):
+        self._check(self.lib.tiny_batch_mpc_step_async(self._h, window_advance))
+
+    def get_x0(self):
+        out = np.empty((self.B, self.nx), np.float32)
+        self._check(self.lib.tiny_batch_get_x0(self._h, _fp(out)))
+        return out
+
+    def synchronize(self):
+        self._check(self.lib.tiny_batch_synchronize(self._h))
+
+    def enable_timing(self, on=True):
+        self._check(self.lib.tiny_batch_enable_timing(self._h, 1 if on else 0))
+
+    def last_solve_ms(self) -> float:
+        ms = C.c_float(0)
+        self._check(self.lib.tiny_batch_last_solve_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def kernel_name(self) -> str:
+        return self.lib.tiny_batch_kernel_name(self._h).decode()
+
+    def select_kernel(self, variant: int):
+        self._check(self.lib.tiny_batch_select_kernel(self._h, variant))
+
+    def set_stream(self, stream_ptr: int):
+        self._check(self.lib.tiny_batch_set_stream(self._h, C.c_void_p(stream_ptr)))

@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — MPC solves/s of the batched TinyMPC ADMM solver on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
+  quadrotor_tracking, nx=12 nu=4 N=30 fp32, 65536 instances per GPU; instance b tracks the window of the
+  301-point y_axis_line trajectory starting at b mod 271 (quadrotor_tracking.cpp:84-85,101), x0_b = Xref_b[0] +
+  U(-0.05,0.05)^12, the reference example's settings (tol 1e-3/1e-3, max_iter 100, check_termination 1, both
+  bounds on, quadrotor_tracking.cpp:75-80), bounds u in [-0.5,0.5], x in [-5,5].
+One "step" = one cold-start tiny_solve() of every instance of the batch: reset_workspace (folded into the solve),
+x0 from a device buffer, per-instance reference windows gathered on the device from the trajectory table, one
+kernel launch running all ADMM iterations with per-instance early exit.  Inputs are resident in HBM before the
+timed region.  The batch shards embarrassingly across ranks (weak scaling: 65536 instances per GPU); there is no
+data-path collective — torch.distributed is used only for the barriers and the max-over-ranks of the time.
+
+Prints ONE JSON line (rank 0).  `roofline` and `cpu_baseline` are described in DESIGN.md §Measurement.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+NX, NU, N = 12, 4, 30
+# ALGORITHMIC cost model of SURVEY.md §8(d) (stated in DESIGN.md):
+#   bytes per solve = every live-in array read once + every live-out array written once, bounds shared
+B_SOLVE = (NX + 3 * NU * (N - 1) + 3 * NX * N + 6 * NX * N + 6 * NU * (N - 1)) * 4 + 24           # 17 208 B
+#   flops per ADMM iteration; the converged iteration omits the backward sweep
+F_FWD = (N - 1) * (2 * NX * NX + 4 * NX * NU + NX + NU) + 2 * NX * NX + 13 * (NX * N + NU * (N - 1))
+F_BWD = (N - 1) * (2 * NX * NX + 4 * NX * NU + 2 * NU * NU + 2 * NX + NU)
+PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
+
+
+def flops_of(iters: np.ndarray, status: np.ndarray) -> float:
+    it = iters.astype(np.float64)
+    return float(np.sum(it * F_FWD + (it - (status == 1)) * F_BWD))
+
+
+def cpu_baseline(prob, pr, seconds_target=12.0):
+    """Time the reference's own CPU path (oracle/_ref, compiled Eigen code, 1 thread — it is single threaded) or,
+    if that prebuilt library is absent, our C port (oracle/), on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    xmn, xmx, umn, umx = pr.bounds_arrays(prob)
+    kind = "reference" if O.have_ref(np.float32, NX, NU, N) else "port"
+    solver = (O.Reference if kind == "reference" else O.Oracle)(prob, np.float32)
+
+    def run(nb, cls_solver, nthreads=1):
+        x0, table, start = pr.tracking_batch(nb, N)
+        st = O.new_state(nb, NX, NU, N)
+        st["x"][:, 0] = x0
+        xr = pr.expand_windows(table, start, N)
+        t0 = time.perf_counter()
+        cls_solver.solve(st, xmn, xmx, umn, umx, xr, nthreads=nthreads)
+        return time.perf_counter() - t0, st
+
+    t_probe, _ = run(256, solver)
+    nb = int(min(65536, max(512, 256 * seconds_target / max(t_probe, 1e-6))))
+    t, st = run(nb, solver)
+    out = dict(value=nb / t, unit="solves/s", cores=1, kind=kind,
+               sample=f"{nb} instances of the same tracking workload, one cold-start tiny_solve each, {t:.1f} s, "
+                      f"mean {st['iter'].mean():.1f} iterations, FTZ/DAZ off, gcc -O3 SSE2")
+    # our multi-threaded C port on all host cores, for scale (not the baseline the reference ships)
+    ncores = os.cpu_count() or 1
+    port = O.Oracle(prob, np.float32)
+    tp, _ = run(256 * ncores, port, ncores)
+    nbp = int(min(65536, max(1024, 256 * ncores * 4.0 / max(tp, 1e-6))))
+    tp, _ = run(nbp, port, ncores)
+    out["port_all_cores"] = dict(value=nbp / tp, unit="solves/s", cores=ncores, kind="port",
+                                 sample=f"{nbp} instances, OpenMP over instances, {tp:.1f} s")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--mode", choices=["early_exit", "fixed10"], default="early_exit")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 streaming, 2 resident")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import accelerated_tinympc_amd as T
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    pr = T.problems
+    prob = pr.quadrotor(20, N)
+    B = args.batch
+    # shard = contiguous block of the global instance index; each rank draws its own block
+    gx0, table, gstart = pr.tracking_batch(B * world, N)
+    x0, start = gx0[rank * B:(rank + 1) * B], gstart[rank * B:(rank + 1) * B]
+    settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1, en_state_bound=1, en_input_bound=1)
+    if args.mode == "fixed10":
+        settings.update(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=10)
+    sol = T.TinyBatchSolver(prob, B, device=local_rank, settings=settings)
+    if args.kernel:
+        sol.select_kernel(args.kernel)
+    sol.set_bounds(*pr.bounds_arrays(prob))
+    sol.set_xref_window(table, start)
+    d_x0 = torch.from_numpy(np.ascontiguousarray(x0)).cuda()
+    lib, h = sol.lib, sol._h
+
+    def step():
+        sol.reset_workspace()
+        sol._check(lib.tiny_batch_set_x0_device(h, C.c_void_p(d_x0.data_ptr())))
+        sol.solve_async()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sol.synchronize()
+    sol.enable_timing(True)
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sol.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms.append(sol.last_solve_ms())  # events of the last timed step (recorded on the launch stream)
+    # per-step kernel durations: a second, untimed pass with an event read after every step
+    for _ in range(min(args.steps, 10)):
+        step()
+        kernel_ms.append(sol.last_solve_ms())
+    n_unsolved = sol.wait()
+    iters, status, _ = sol.get_status()
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([float(iters.sum()), float((status == 1).sum()), flops_of(iters, status), float(iters.max())],
+                         dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        mx = stats[3:].clone()
+        dist.all_reduce(stats[:3], op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        stats[3:] = mx
+    dt = float(t.item())
+    total_solves = B * world * args.steps
+    value = total_solves / dt
+
+    if rank == 0:
+        k_ms = float(np.mean(kernel_ms))
+        fl = flops_of(iters, status)  # this rank's launch
+        t_mem = B * B_SOLVE / (PEAK_HBM_GBS * 1e9)
+        t_flop = fl / (PEAK_F32_TFLOPS * 1e12)
+        hbm_ach = B * B_SOLVE / (k_ms * 1e-3) / 1e9
+        fl_ach = fl / (k_ms * 1e-3) / 1e12
+        traffic = None
+        tf = ROOT / "profiles" / "hbm_traffic.json"
+        if tf.exists():
+            try:
+                traffic = json.loads(tf.read_text()).get(f"{sol.kernel_name()}:{args.mode}:{B}")
+            except Exception:
+                traffic = None
+        if t_flop >= t_mem:
+            roof = dict(bound="mfma", achieved=fl_ach, peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=fl_ach / PEAK_F32_TFLOPS,
+                        traffic=traffic)
+        else:
+            roof = dict(bound="hbm", achieved=hbm_ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm_ach / PEAK_HBM_GBS,
+                        traffic=traffic)
+        roof.update(kernel=sol.kernel_name(), kernel_ms=k_ms, hbm_GBs=hbm_ach, hbm_frac=hbm_ach / PEAK_HBM_GBS,
+                    f32_TFLOPs=fl_ach, f32_frac=fl_ach / PEAK_F32_TFLOPS, alg_bytes_per_solve=B_SOLVE,
+                    alg_flops_per_launch=fl, note="fp32 vector/MFMA peak 157.3 TFLOP/s; the path is not a dense "
+                    "GEMM, 'mfma' here means the fp32 FMA roof (vector == f32-MFMA peak on gfx950)")
+        line = {
+            "metric": "MPC solves/sec (batched quadrotor nx=12,nu=4,N=30)", "value": value, "unit": "solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"quadrotor_tracking batched {B} instances per GPU, cold-start tiny_solve, "
+                                   f"{args.mode} (tol 1e-3, max_iter 100)" if args.mode == "early_exit" else
+                                   f"quadrotor_tracking batched {B} instances per GPU, cold-start tiny_solve, fixed 10 iterations",
+                       "nx": NX, "nu": NU, "N": N, "instances_per_gpu": B, "parallelism": f"batch-shard x{world}",
+                       "kernel": sol.kernel_name(), "mean_iters": float(stats[0].item()) / (B * world),
+                       "max_iters": int(stats[3].item()), "frac_converged": float(stats[1].item()) / (B * world)},
+            "roofline": roof,
+        }
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(prob, pr)
+        print(json.dumps(line), flush=True)
+    sol.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

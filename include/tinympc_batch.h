@@ -1,0 +1,149 @@
+/*
+ * tinympc_batch.h — C-ABI of the MI355X-native batched TinyMPC ADMM solver.
+ *
+ * Drop-in boundary for ONE path of ucb-bar/Accelerated-TinyMPC: tiny_solve()
+ * (src/tinympc/admm.cpp:111-152) and the flat-float* wrapper the reference generates
+ * for foreign-language callers (src/tinympc/tiny_wrapper.hpp:14-23), re-expressed over a
+ * batch of B independent problem instances of one problem class (nx, nu, N).
+ *
+ * Conventions
+ *  - plain C, plain pointers and sizes; no C++/torch/Eigen types cross this boundary.
+ *  - every function returns TINY_BATCH_OK (0) or a negative TinyBatchError unless noted;
+ *    tiny_batch_last_error() returns a human-readable message for the calling thread.
+ *  - matrices (Kinf, Adyn, ...) are COLUMN-MAJOR, the storage order of the reference's Eigen
+ *    members (src/tinympc/types.hpp:13-21): element (i,j) of an R x C matrix is at j*R+i.
+ *  - batched arrays use the array-of-reference-instances layout: state-type arrays are
+ *    [B][N][nx], input-type arrays are [B][N-1][nu] (instance-major, then horizon step,
+ *    then state index) = the flat order tiny_wrapper.cpp uses (xref[j*NSTATES+i], :27)
+ *    repeated per instance.  The device-internal layout is private to the library.
+ *  - pointers are HOST pointers unless the function name ends in _device.
+ *  - the workspace is device-resident and persists between solves (that IS the warm start:
+ *    examples/quadrotor_hovering.cpp:99-101 only resets y and g).
+ *  - float only: the reference's wrapper is float-only too (tiny_wrapper.cpp:154,167) and its
+ *    code generator always emits `typedef float tinytype` (src/tinympc/codegen.cpp:152).
+ *
+ * Not thread-safe per handle; distinct handles may be used from distinct threads.
+ */
+#ifndef TINYMPC_BATCH_H
+#define TINYMPC_BATCH_H
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+    typedef struct TinyBatch TinyBatch;
+
+    typedef enum
+    {
+        TINY_BATCH_OK = 0,
+        TINY_BATCH_EINVAL = -1,      /* bad argument / NULL pointer / size mismatch */
+        TINY_BATCH_EHIP = -2,        /* a HIP runtime call failed (message has the hipError string) */
+        TINY_BATCH_EUNSUPPORTED = -3,/* (nx, nu) has no compiled kernel instantiation */
+        TINY_BATCH_ENOTREADY = -4    /* cache / dynamics / settings not set before solve */
+    } TinyBatchError;
+
+    /* status codes stored per instance, as the reference's work->status (admm.cpp:114,136) */
+#define TINY_STATUS_SOLVED 1
+#define TINY_STATUS_UNSOLVED 11
+
+    /* Workspace array ids, in the member order of TinyWorkspace (types.hpp:52-97). */
+    typedef enum
+    {
+        TINY_ARR_X = 0, TINY_ARR_U = 1, TINY_ARR_Q = 2, TINY_ARR_R = 3, TINY_ARR_P = 4, TINY_ARR_D = 5,
+        TINY_ARR_V = 6, TINY_ARR_VNEW = 7, TINY_ARR_Z = 8, TINY_ARR_ZNEW = 9, TINY_ARR_G = 10, TINY_ARR_Y = 11,
+        TINY_ARR_COUNT = 12
+    } TinyBatchArray;
+
+    const char *tiny_batch_last_error(void);
+
+    /* ---- lifetime --------------------------------------------------------------------------- */
+    /* Allocates the device-resident workspaces of `batch` instances on HIP device `device`, all
+     * zero (the state the reference examples start from, quadrotor_hovering.cpp:49-71).
+     * Replaces: the caller-owned TinyCache/TinyWorkspace/TinySettings/TinySolver globals
+     * (types.hpp:26-107, quadrotor_hovering.cpp:25-28). */
+    int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int device);
+    void tiny_batch_destroy(TinyBatch *tb);
+    /* Launch on this hipStream_t (passed as void*; NULL = the null stream).  Default: NULL. */
+    int tiny_batch_set_stream(TinyBatch *tb, void *hip_stream);
+    int tiny_batch_synchronize(TinyBatch *tb);
+
+    /* ---- problem class (shared by all instances) ------------------------------------------- */
+    /* TinyCache{rho,Kinf,Pinf,Quu_inv,AmBKt} (types.hpp:26-34); coeff_d2p is never read by tiny_solve. */
+    int tiny_batch_set_cache(TinyBatch *tb, float rho, const float *Kinf /*nu x nx*/, const float *Pinf /*nx x nx*/,
+                             const float *Quu_inv /*nu x nu*/, const float *AmBKt /*nx x nx*/);
+    /* work->Adyn, work->Bdyn, work->Q (types.hpp:82-85); work->R/Qu/Uref are never read (admm.cpp:79). */
+    int tiny_batch_set_dynamics(TinyBatch *tb, const float *Adyn /*nx x nx*/, const float *Bdyn /*nx x nu*/,
+                                const float *Q /*nx*/);
+    /* TinySettings (types.hpp:39-47), same field meaning. */
+    int tiny_batch_set_settings(TinyBatch *tb, float abs_pri_tol, float abs_dua_tol, int max_iter,
+                                int check_termination, int en_state_bound, int en_input_bound);
+
+    /* ---- batched twins of the wrapper calls (tiny_wrapper.hpp:14-23) ------------------------- */
+    int tiny_batch_set_x0(TinyBatch *tb, const float *x0 /*[B][nx]*/);                       /* set_x0   :14 */
+    /* shared != 0: one [N][nx] reference for the whole batch */
+    int tiny_batch_set_xref(TinyBatch *tb, const float *xref /*[B][N][nx]*/, int shared);    /* set_xref :15 */
+    /* Xref_b = table[start[b] .. start[b]+N): the sliding window of quadrotor_tracking.cpp:84-85,101,
+     * gathered on the device from one shared trajectory table. */
+    int tiny_batch_set_xref_window(TinyBatch *tb, const float *table /*[rows][nx]*/, int rows,
+                                   const int *start /*[B]*/);
+    int tiny_batch_set_umin(TinyBatch *tb, const float *umin /*[B][N-1][nu]*/, int shared);  /* set_umin :16 */
+    int tiny_batch_set_umax(TinyBatch *tb, const float *umax, int shared);                   /* set_umax :17 */
+    int tiny_batch_set_xmin(TinyBatch *tb, const float *xmin /*[B][N][nx]*/, int shared);    /* set_xmin :18 */
+    int tiny_batch_set_xmax(TinyBatch *tb, const float *xmax, int shared);                   /* set_xmax :19 */
+    int tiny_batch_reset_dual_variables(TinyBatch *tb);                                      /* reset_dual_variables :20 */
+    /* call_tiny_solve :21 / tiny_solve (admm.hpp:10).  Synchronous.  Returns 0 if every instance
+     * converged (tiny_solve returned 0 for all), 1 if at least one hit max_iter (tiny_solve returned 1),
+     * negative on error. */
+    int tiny_batch_solve(TinyBatch *tb);
+    int tiny_batch_get_x(TinyBatch *tb, float *x /*[B][N][nx]*/);                            /* get_x :22 */
+    int tiny_batch_get_u(TinyBatch *tb, float *u /*[B][N-1][nu]*/);                          /* get_u :23 */
+    /* per-instance work->iter, work->status and the four residual fields in the order
+     * {primal_residual_state, primal_residual_input, dual_residual_state, dual_residual_input}.
+     * Any pointer may be NULL. */
+    int tiny_batch_get_status(TinyBatch *tb, int *iter /*[B]*/, int *status /*[B]*/, float *residuals /*[B][4]*/);
+
+    /* ---- asynchronous form ----------------------------------------------------------------- */
+    int tiny_batch_solve_async(TinyBatch *tb);                 /* enqueue on the stream, do not wait */
+    /* wait for the stream; *n_unsolved = number of instances whose tiny_solve returned 1 */
+    int tiny_batch_wait(TinyBatch *tb, int *n_unsolved);
+
+    /* ---- whole-workspace access (warm-start upload, parity tests) ---------------------------- */
+    int tiny_batch_set_array(TinyBatch *tb, int array_id, const float *src);
+    int tiny_batch_get_array(TinyBatch *tb, int array_id, float *dst);
+    int tiny_batch_set_status(TinyBatch *tb, const int *iter, const int *status, const float *residuals);
+    /* zero every work array, residuals, status and iter (cold start) */
+    int tiny_batch_reset_workspace(TinyBatch *tb);
+
+    /* ---- device-pointer forms (no host round trip) ------------------------------------------ */
+    int tiny_batch_set_x0_device(TinyBatch *tb, const float *d_x0 /*[B][nx]*/);
+    int tiny_batch_get_u0_device(TinyBatch *tb, float *d_u0 /*[B][nu] = u.col(0) of every instance*/);
+
+    /* ---- closed loop on the device (quadrotor_hovering.cpp:90-114 / quadrotor_tracking.cpp:93-118) ------
+     * One MPC step for every instance without touching the host:
+     *   x.col(0) = x0;  [window start += window_advance];  y = 0, g = 0;  tiny_solve;  x0 = Adyn*x0 + Bdyn*u.col(0)
+     * x0 lives in an internal device buffer seeded by tiny_batch_set_x0(). */
+    int tiny_batch_mpc_step_async(TinyBatch *tb, int window_advance);
+    int tiny_batch_get_x0(TinyBatch *tb, float *x0 /*[B][nx]*/);
+
+    /* ---- measurement ------------------------------------------------------------------------- */
+    /* When enabled, every solve records hipEvents around its kernel launches on the stream. */
+    int tiny_batch_enable_timing(TinyBatch *tb, int on);
+    /* Synchronises and returns the device time in ms of the most recent solve's kernel(s). */
+    int tiny_batch_last_solve_ms(TinyBatch *tb, float *ms);
+    /* Name of the kernel variant the next solve will launch ("stream<3,1>", "resident<3,1,30>", ...). */
+    const char *tiny_batch_kernel_name(TinyBatch *tb);
+    /* Force a kernel variant: 0 = auto, 1 = streaming (state in HBM), 2 = resident (state on chip). */
+    int tiny_batch_select_kernel(TinyBatch *tb, int variant);
+
+    /* ---- offline setup: Riccati cache precompute (src/tinympc/codegen.cpp:254-292), fp64, host ---- */
+    /* A (nx x nx), B (nx x nu) column-major; Q (nx), R (nu) diagonals WITHOUT rho (the routine adds it,
+     * codegen.cpp:255-256).  Outputs column-major.  *iters = Riccati iterations run (1000 = not converged,
+     * the reference then keeps the last iterate too).  coeff_d2p may be NULL. */
+    int tiny_riccati(int nx, int nu, const double *A, const double *B, const double *Q, const double *R, double rho,
+                     double *Kinf, double *Pinf, double *Quu_inv, double *AmBKt, double *coeff_d2p, int *iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYMPC_BATCH_H */

@@ -1,0 +1,97 @@
+"""CPU tests: the oracle (our C restatement) against the compiled reference's golden vectors,
+and, where oracle/_ref is present, bit-for-bit against the compiled reference itself."""
+import numpy as np
+import pytest
+
+from helpers import STATE_ORDER, bounds_of, load_fixture
+
+FIXTURES = ["quad_hover_f32_N30", "quad_hover_f64_N10", "quad_track_f32_N30", "quad_batch_f32_N30",
+            "quad_trackbatch_f32_N30", "cartpole_f32_N10", "random_f32_32_16_50", "dims_f32_8_3_7"]
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_oracle_reproduces_golden_bit_exact(oracle_mod, name):
+    """Every golden solve (live-in -> live-out of the reference's tiny_solve) is reproduced exactly."""
+    O = oracle_mod
+    meta, prob, solves, _ = load_fixture(name)
+    dt = np.dtype(meta["dtype"])
+    xmn, xmx, umn, umx = bounds_of(prob, dt)
+    for s in solves:
+        orc = O.Oracle(prob, dt, s["settings"])
+        st = {k: v.copy() for k, v in s["pre"].items()}
+        rc = orc.solve(st, xmn, xmx, umn, umx, s["xref"])
+        assert (rc > 0) == (s["rc"] > 0)
+        for k in STATE_ORDER + ("residuals", "status", "iter"):
+            assert np.array_equal(st[k], s["post"][k]), (name, s["k"], k, np.max(np.abs(st[k] - s["post"][k])))
+
+
+def test_known_answers_of_the_survey(oracle_mod):
+    """SURVEY.md §4 KATs of the unchanged reference, via the golden traces."""
+    meta, prob, solves, z = load_fixture("quad_hover_f64_N10")
+    np.testing.assert_allclose(z["trace_u0"][0], [0.488778532, 0.478938215, 0.542743696, 0.551056731], rtol=0, atol=5e-10)
+    assert int(z["trace_iter"].sum()) == 1269 and z["trace_iter"][0] == 100 and z["trace_iter"][69] == 2
+    assert z["trace_status"][0] == 11 and z["trace_status"][69] == 1 and z["trace_rc"][0] == 1 and z["trace_rc"][69] == 0
+    meta, prob, solves, z = load_fixture("quad_hover_f32_N30")
+    np.testing.assert_allclose(z["trace_u0"][0], [0.48478967, 0.476141721, 0.531687975, 0.539531589], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(solves[0]["post"]["residuals"][0], [0, 3.953e-2, 2.403e-2, 7.488e-3], rtol=2e-3, atol=0)
+    assert z["trace_iter"][0] == 100 and z["trace_iter"][69] == 2
+
+
+def test_max_iter_zero_touches_only_status_and_iter(oracle_mod):
+    """admm.cpp:114-117,151: with max_iter=0 tiny_solve returns 1, status=11, iter=1, nothing else changes."""
+    O = oracle_mod
+    meta, prob, solves, _ = load_fixture("quad_hover_f32_N30")
+    s = solves[2]
+    xmn, xmx, umn, umx = bounds_of(prob, np.float32)
+    st = {k: v.copy() for k, v in s["pre"].items()}
+    rc = O.Oracle(prob, np.float32, dict(s["settings"], max_iter=0)).solve(st, xmn, xmx, umn, umx, s["xref"])
+    assert rc == 1 and st["status"][0] == 11 and st["iter"][0] == 1
+    for k in STATE_ORDER + ("residuals",):
+        assert np.array_equal(st[k], s["pre"][k])
+
+
+CFGS = [(np.float32, 12, 4, 30), (np.float64, 12, 4, 30), (np.float64, 12, 4, 10), (np.float32, 12, 4, 10),
+        (np.float32, 4, 1, 10), (np.float64, 4, 1, 10), (np.float32, 8, 3, 7), (np.float32, 32, 16, 50)]
+
+
+@pytest.mark.parametrize("dt,nx,nu,N", CFGS)
+def test_oracle_bit_exact_vs_compiled_reference(oracle_mod, tinympc, dt, nx, nu, N):
+    """Random warm-start states and references through the compiled reference (oracle/_ref) and the oracle."""
+    O = oracle_mod
+    if not O.have_ref(dt, nx, nu, N):
+        pytest.skip("oracle/_ref not built here (needs /root/reference)")
+    pr = tinympc.problems
+    if (nx, nu) == (12, 4):
+        prob = pr.quadrotor(20, N)
+    elif (nx, nu) == (4, 1):
+        prob = pr.cartpole(N, riccati=O.riccati)
+    else:
+        prob = pr.random_system(nx, nu, N, seed=nx * 100 + nu, riccati=O.riccati)
+    rng = np.random.default_rng(nx + nu + N)
+    B = 5
+    st0 = O.new_state(B, nx, nu, N, dt)
+    for k in STATE_ORDER:
+        st0[k][:] = (rng.standard_normal(st0[k].shape) * 0.3).astype(dt)
+    xref = (rng.standard_normal((B, N, nx)) * 0.2).astype(dt)
+    xmn, xmx, umn, umx = pr.bounds_arrays(prob, dt)
+    for settings in (dict(max_iter=1, abs_pri_tol=0, abs_dua_tol=0), dict(max_iter=12, abs_pri_tol=0, abs_dua_tol=0),
+                     dict(max_iter=60, check_termination=3), dict(max_iter=5, en_state_bound=0, en_input_bound=0)):
+        a, b = O.copy_state(st0), O.copy_state(st0)
+        ra = O.Oracle(prob, dt, settings).solve(a, xmn, xmx, umn, umx, xref)
+        rb = O.Reference(prob, dt, settings).solve(b, xmn, xmx, umn, umx, xref)
+        assert ra == rb
+        for k in STATE_ORDER + ("residuals", "status", "iter"):
+            assert np.array_equal(a[k], b[k]), (settings, k)
+
+
+def test_riccati_oracle_vs_reference_codegen(oracle_mod):
+    """oracle_riccati (codegen.cpp:254-292 restated) against the cache the reference's tiny_codegen() emitted."""
+    O = oracle_mod
+    for name, nx, nu in (("riccati_cartpole", 4, 1), ("riccati_random_32_16", 32, 16)):
+        z = np.load(__import__("helpers").GOLDEN / f"{name}.npz")
+        c, it = O.riccati(nx, nu, z["A"], z["B"], z["Q"], z["R"], float(z["rho"]))
+        for k in ("Kinf", "Pinf", "Quu_inv", "AmBKt"):
+            np.testing.assert_allclose(c[k], z[k], rtol=1e-9, atol=1e-9 * np.max(np.abs(z[k])))
+        if nx == 4:
+            assert it == 476  # "Kinf converged after 476 iterations" 
+            np.testing.assert_allclose(c["Kinf"].ravel(), [-2.9121762, -4.8173684, 44.3538696, 19.7167444], atol=1e-7)
