@@ -226,6 +226,9 @@ __global__ __launch_bounds__(WAVE) void admm_stream_kernel(const SolveParams P)
         if (!__any(active)) break;
         const bool zero_duals = (it == 0) && ((P.duals_zero | P.cold_start) != 0);
         const bool zero_state = (it == 0) && (P.cold_start != 0);
+        // an instance that exhausts max_iter has its d overwritten by the last backward sweep, so its x,u (which
+        // belong to the last FORWARD sweep) are stored here; converged instances regenerate theirs at the end.
+        const bool keep_xu = active && (it == P.max_iter - 1);
         float pri_x = 0.f, dua_x = 0.f, pri_u = 0.f, dua_u = 0.f;
         float xs[NXC], pN[NXC];
 #pragma unroll
@@ -275,6 +278,7 @@ __global__ __launch_bounds__(WAVE) void admm_stream_kernel(const SolveParams P)
             }
             stv<NXC>(P.vnew + xo, vn, active);
             stv<NXC>(P.g + xo, g, active);
+            stv<NXC>(P.x + xo, xs, keep_xu);
             if (i < N - 1)
             {
                 const size_t uo = ubase + (size_t)i * ustep;
@@ -306,6 +310,7 @@ __global__ __launch_bounds__(WAVE) void admm_stream_kernel(const SolveParams P)
                 }
                 stv<NUC>(P.znew + uo, zn, active);
                 stv<NUC>(P.y + uo, y, active);
+                stv<NUC>(P.u + uo, us, keep_xu);
 #pragma unroll
                 for (int k = 0; k < NXC; k++) xs[k] = xn[k];
             }
@@ -385,8 +390,8 @@ __global__ __launch_bounds__(WAVE) void admm_stream_kernel(const SolveParams P)
     }
 
     // ---------------- outputs: x,u of the last executed iteration, r and q ----------------
-    // x and u are regenerated from the frozen d (the same instruction sequence as the sweep that
-    // produced them => bit-identical) instead of being stored on every iteration.
+    // For converged instances x and u are regenerated from the frozen d (the same instruction sequence as the
+    // sweep that produced them => bit-identical) instead of being stored on every iteration.
     {
         float xs[NXC];
 #pragma unroll
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(WAVE) void admm_stream_kernel(const SolveParams P)
                 q[k] = t - rho * (vn[k] - g[k]);
             }
             stv<NXC>(P.q + xo, q, valid);
-            stv<NXC>(P.x + xo, xs, valid);
+            stv<NXC>(P.x + xo, xs, valid && st == TINY_STATUS_SOLVED_);
             if (i < N - 1)
             {
                 const size_t uo = ubase + (size_t)i * ustep;
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(WAVE) void admm_stream_kernel(const SolveParams P)
                 lqr_step<D>(op, xs, dd, us, xn);
 #pragma unroll
                 for (int m = 0; m < NUC; m++) r[m] = -rho * (zn[m] - y[m]);
-                stv<NUC>(P.u + uo, us, valid);
+                stv<NUC>(P.u + uo, us, valid && st == TINY_STATUS_SOLVED_);
                 stv<NUC>(P.r + uo, r, valid);
 #pragma unroll
                 for (int k = 0; k < NXC; k++) xs[k] = xn[k];

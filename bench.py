@@ -65,20 +65,30 @@ def cpu_baseline(prob, pr, seconds_target=12.0):
         cls_solver.solve(st, xmn, xmx, umn, umx, xr, nthreads=nthreads)
         return time.perf_counter() - t0, st
 
+    def timed(solver_, nthreads, budget_s, chunk):
+        """repeat cold-start passes over `chunk` instances until ~budget_s of wall time has been spent"""
+        n, t, its = 0, 0.0, []
+        while t < budget_s:
+            dt, st = run(chunk, solver_, nthreads)
+            n += chunk; t += dt; its.append(st["iter"].mean())
+        return n, t, float(np.mean(its))
+
     t_probe, _ = run(256, solver)
-    nb = int(min(65536, max(512, 256 * seconds_target / max(t_probe, 1e-6))))
-    t, st = run(nb, solver)
+    chunk = int(min(32768, max(256, 256 * 2.0 / max(t_probe, 1e-6))))
+    nb, t, mi = timed(solver, 1, seconds_target, chunk)
     out = dict(value=nb / t, unit="solves/s", cores=1, kind=kind,
-               sample=f"{nb} instances of the same tracking workload, one cold-start tiny_solve each, {t:.1f} s, "
-                      f"mean {st['iter'].mean():.1f} iterations, FTZ/DAZ off, gcc -O3 SSE2")
-    # our multi-threaded C port on all host cores, for scale (not the baseline the reference ships)
-    ncores = os.cpu_count() or 1
+               sample=f"{nb} cold-start tiny_solve calls on the same tracking workload ({chunk}-instance passes), "
+                      f"{t:.1f} s, mean {mi:.1f} iterations, FTZ/DAZ off, g++ -O3 SSE2 (the build SURVEY.md probed)")
+    # our multi-threaded C port on the host cores this process may use, for scale (not what the reference ships)
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, 16))
     port = O.Oracle(prob, np.float32)
-    tp, _ = run(256 * ncores, port, ncores)
-    nbp = int(min(65536, max(1024, 256 * ncores * 4.0 / max(tp, 1e-6))))
-    tp, _ = run(nbp, port, ncores)
+    nbp, tp, _ = timed(port, ncores, 4.0, 4096 * ncores)
     out["port_all_cores"] = dict(value=nbp / tp, unit="solves/s", cores=ncores, kind="port",
-                                 sample=f"{nbp} instances, OpenMP over instances, {tp:.1f} s")
+                                 sample=f"{nbp} solves, OpenMP over instances, {tp:.1f} s")
     return out
 
 
