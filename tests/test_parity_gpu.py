@@ -17,9 +17,9 @@ FAST arithmetic (fma chains: v_mfma_f32_16x16x4_f32 in the streaming kernel, v_f
   same inputs with the fp64 oracle (bit-exact with the reference's fp64 build, tests/test_oracle.py):
     * per array, over instances whose iteration count agrees, relative inf-norm error (normalised by
       max(|ref|_inf, natural scale)) <= 3 x the fp64-vs-fp32 spread of the same array, with an absolute
-      floor of 2e-5 (u, z, znew, duals) / 5e-5 (x, v, vnew) for tiny batches;
+      floor of 2e-5 (u, z, znew) / 5e-5 (everything else) for tiny batches;
     * fraction of instances whose iteration count differs from the fp32 reference <= max(1.5 x the
-      fp64-vs-fp32 fraction, 2 %), and never by more than the fp64 spread + 2 iterations;
+      fp64-vs-fp32 fraction, 2 %), and never by more than the fp64 spread + 2 termination checks;
     * hard cap regardless of the yardstick: u within 2e-4 of the reference relative to the input bound.
 """
 import numpy as np
@@ -59,12 +59,12 @@ def assert_bitwise(got, ref, what):
     return 0
 
 
-def compare_states(got, ref, prob, what, ref64=None, exact=False):
+def compare_states(got, ref, prob, what, ref64=None, exact=False, fixed=False, ct=1):
     if exact:
         return assert_bitwise(got, ref, what)
     same = (got["iter"] == ref["iter"]) & (got["status"] == ref["status"])
     nflip = int((~same).sum())
-    if ref64 is None:  # fixed-iteration solves: the iteration count cannot legitimately change
+    if fixed or ref64 is None:  # fixed-iteration solves: the iteration count cannot legitimately change
         assert nflip == 0, f"{what}: iter/status differ for {nflip} instances"
         same64 = np.ones_like(same)
     else:
@@ -74,12 +74,12 @@ def compare_states(got, ref, prob, what, ref64=None, exact=False):
             f"{what}: {nflip}/{same.size} iteration-count changes vs fp32 reference; the reference's own fp64 build changes {f64:.3f}"
         if nflip:
             spread = int(np.abs(ref64["iter"] - ref["iter"]).max())
-            assert int(np.abs(got["iter"][~same] - ref["iter"][~same]).max()) <= spread + 2, what
+            assert int(np.abs(got["iter"][~same] - ref["iter"][~same]).max()) <= spread + 2 * ct, what  # exits only happen every ct iterations
     if same.any():
         for k in STATE_ORDER:
             fl = _floor(k, prob, ref[k])
             e = rel_inf(got[k][same], ref[k][same], fl)
-            bar = 5e-5 if k in PRIMAL_X else 2e-5
+            bar = 2e-5 if k in PRIMAL_U else 5e-5  # g, q, p inherit the x-type error through x - vnew
             if ref64 is not None and same64.any():
                 bar = max(bar, 3.0 * float(rel_inf(ref64[k][same64], ref[k][same64], fl).max()))
             assert e.max() <= bar, f"{what}: array {k} rel-inf error {e.max():.3e} > {bar:.3e} (instance {int(e.argmax())})"
@@ -124,8 +124,8 @@ def test_golden_vectors(tinympc, oracle_mod, variant, name):
         rc = sol.solve()
         got = sol.get_state()
         fixed = s["settings"]["abs_pri_tol"] == 0
-        r64 = None if (fixed or exact) else yardstick(oracle_mod, prob, s["settings"], s["pre"], s["xref"], bnds)
-        nf = compare_states(got, s["post"], prob, f"{name}[k={s['k']}] {variant}", ref64=r64, exact=exact)
+        r64 = None if exact else yardstick(oracle_mod, prob, s["settings"], s["pre"], s["xref"], bnds)
+        nf = compare_states(got, s["post"], prob, f"{name}[k={s['k']}] {variant}", ref64=r64, exact=exact, fixed=fixed)
         if nf == 0:
             assert rc == (1 if s["rc"] > 0 else 0)
         sol.close()
@@ -180,8 +180,8 @@ def test_ragged_batches_vs_oracle(tinympc, oracle_mod, variant, B):
             orc.solve(st, *bnds, xref, nthreads=8)
             sol.solve()
             got = sol.get_state()
-            r64 = None if (fixed or exact) else yardstick(O, prob, settings, pre, xref, bnds)
-            compare_states(got, st, prob, f"B={B} k={k} fixed={fixed} {variant}", ref64=r64, exact=exact)
+            r64 = None if exact else yardstick(O, prob, settings, pre, xref, bnds)
+            compare_states(got, st, prob, f"B={B} k={k} fixed={fixed} {variant}", ref64=r64, exact=exact, fixed=fixed)
             if not exact:
                 sol.set_state(st)  # re-synchronise so the next warm start compares like with like
         sol.close()
@@ -227,8 +227,9 @@ def test_settings_variants_vs_oracle(tinympc, oracle_mod, variant):
         orc.solve(st, *bnds, xref, nthreads=8)
         sol.solve()
         fixed = settings["abs_pri_tol"] == 0 or settings["max_iter"] == 1
-        r64 = None if (fixed or exact) else yardstick(O, prob, settings, pre, xref, bnds)
-        compare_states(sol.get_state(), st, prob, f"variant {over} {variant}", ref64=r64, exact=exact)
+        r64 = None if exact else yardstick(O, prob, settings, pre, xref, bnds)
+        compare_states(sol.get_state(), st, prob, f"variant {over} {variant}", ref64=r64, exact=exact, fixed=fixed,
+                       ct=settings["check_termination"])
         sol.close()
 
 
