@@ -15,7 +15,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libtinympc_hip.so"
-SOURCES = ["tinympc_batch.hip", "admm_stream.hip", "admm_resident.hip", "riccati.cpp"]
+SOURCES = ["tinympc_batch.hip", "admm_stream.hip", "admm_rowlane.hip", "riccati.cpp"]
 HEADERS = [CSRC / "tinympc_internal.h", PKG.parent / "include" / "tinympc_batch.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-gpu-rdc"]
 

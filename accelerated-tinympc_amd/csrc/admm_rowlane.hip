@@ -1,0 +1,421 @@
+// admm_rowlane.hip — register-resident batched TinyMPC ADMM kernel for small problems (nx + nu <= 16).
+//
+// Restates tiny_solve() (src/tinympc/admm.cpp:111-152) with the WHOLE loop-carried state of an
+// instance (d, y, g, v, z, plus vnew/znew and p) held in VGPRs for the entire solve: HBM is touched
+// only to read the live-in arrays once and to write the live-out arrays once.
+//
+// Mapping ("row lanes"): a DPP row = 16 lanes = ONE instance, 4 instances per wavefront.  Lane r of
+// the row owns row r of the stacked vector [x ; u]: r < NX -> x(r), NX <= r < NX+NU -> u(r-NX)
+// (quadrotor: 12 + 4 = exactly 16).  A gain x state product y = M s is NX (or NU) instructions
+//      t_k = M[r][k] * s[k]      with s[k] fetched by the DPP modifier row_newbcast:k
+// i.e. the cross-lane broadcast is free (an operand modifier of v_mul_f32 / v_fmac_f32), the gain
+// row sits in the lane's own VGPRs, and the x rows (A, AmBKt) and the u rows (Kinf, Bdyn^T) of a
+// sweep step execute in the same instructions.  Everything is unrolled over the horizon so that the
+// state arrays index registers statically.
+//
+// Two arithmetic modes (template parameter EXACT):
+//   EXACT = true : every product and every sum is a separately rounded fp32 operation, summed in the
+//                  order the reference's SSE2 Eigen build uses (seq / halving tree / packet tree, see RowPlans below;
+//                  Eigen/src/Core/Redux.h, ProductEvaluators.h, GeneralProduct.h of the vendored Eigen 3.4.90).
+//                  Results are BITWISE identical to the compiled reference, iteration counts included.
+//   EXACT = false: one v_fmac_f32_dpp per multiply-add (k-ascending fma chain), ~2x fewer instructions.
+#include "tinympc_internal.h"
+#include "dpp_ops_gen.h"
+
+namespace tinympc
+{
+
+// DPP row-broadcast multiply / multiply-accumulate chains: dpp_products, dpp_fma_dot, dpp_fma_acc.
+// hipcc does not fold v_mov_b32_dpp into v_fmac_f32 and separates consecutive asm statements by an s_nop,
+// so every chain is ONE generated inline-asm statement (tools/gen_dpp_ops.py).  A VALU write of `src`
+// followed by a DPP read of it needs two wait states which the compiler does not track inside asm: every
+// chain starts with s_nop 1.
+// ---------------------------------------------------------------------------------------------
+// Reduction orders of the reference build.  Eigen 3.4.90 picks them at compile time from storage order, sizes and
+// the SSE2 packet size (4 floats):
+//   SEQ  ((t0+t1)+t2)+...            packet-evaluated lazy products (result rows a multiple of 4: etor_product_packet_impl)
+//   TREE T(lo,n) = T(lo,n/2) + T(lo+n/2, n-n/2)   coefficient-evaluated, completely unrolled redux (redux_novec_unroller),
+//        taken while 3n-1 <= EIGEN_UNROLLING_LIMIT = 110, else SEQ
+//   VEC  products grouped in packets of 4, packets summed by the same halving tree (redux_vec_unroller), then
+//        predux (s0+s2)+(s1+s3), then the n%4 leftover (TREE) added; TREE when n < 4
+// The parity tests check the result bit for bit against vectors produced by the compiled reference.
+// ---------------------------------------------------------------------------------------------
+enum : int { PLAN_SEQ = 0, PLAN_TREE = 1, PLAN_VEC = 2 };
+constexpr int plan_novec(int n) { return (3 * n - 1 <= 110) ? PLAN_TREE : PLAN_SEQ; }
+constexpr int plan_vec(int n) { return n < 4 ? plan_novec(n) : PLAN_VEC; }
+
+template <int LO, int CNT, int NN>
+__device__ __forceinline__ float tree_sum(const float (&t)[NN])
+{
+    if constexpr (CNT == 1) return t[LO];
+    else
+    {
+        constexpr int H = CNT / 2;
+        return tree_sum<LO, H>(t) + tree_sum<LO + H, CNT - H>(t);
+    }
+}
+template <int PLO, int PCNT, int L, int NN>
+__device__ __forceinline__ float ptree_sum(const float (&t)[NN]) // lane L of the packets [PLO, PLO+PCNT)
+{
+    if constexpr (PCNT == 1) return t[4 * PLO + L];
+    else
+    {
+        constexpr int H = PCNT / 2;
+        return ptree_sum<PLO, H, L>(t) + ptree_sum<PLO + H, PCNT - H, L>(t);
+    }
+}
+template <int PLAN, int NN>
+__device__ __forceinline__ float reduce(const float (&t)[NN])
+{
+    if constexpr (NN == 1) return t[0];
+    else if constexpr (PLAN == PLAN_SEQ)
+    {
+        float acc = t[0];
+#pragma unroll
+        for (int k = 1; k < NN; k++) acc = acc + t[k];
+        return acc;
+    }
+    else if constexpr (PLAN == PLAN_TREE) return tree_sum<0, NN>(t);
+    else
+    {
+        constexpr int NPK = NN / 4;
+        const float s0 = ptree_sum<0, NPK, 0>(t), s1 = ptree_sum<0, NPK, 1>(t), s2 = ptree_sum<0, NPK, 2>(t),
+                    s3 = ptree_sum<0, NPK, 3>(t);
+        float res = (s0 + s2) + (s1 + s3); // SSE2 predux
+        if constexpr (NN % 4 != 0) res = res + tree_sum<4 * NPK, NN - 4 * NPK>(t);
+        return res;
+    }
+}
+
+// max over the 16 lanes of a DPP row; every lane gets the result
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_max(float v)
+{
+    v = fmaxf(v, dpp_mov<0x128>(v)); // row_ror:8
+    v = fmaxf(v, dpp_mov<0x124>(v)); // row_ror:4
+    v = fmaxf(v, dpp_mov<0x122>(v)); // row_ror:2
+    v = fmaxf(v, dpp_mov<0x121>(v)); // row_ror:1
+    return v;
+}
+
+template <int NX, int NU>
+struct RowPlans
+{
+    static_assert(NX > 1 && NU >= 1 && NX + NU <= 16, "rowlane kernel needs 1 < nx, nx + nu <= 16");
+    static_assert(!(NU >= 8 && NX >= 8), "Eigen switches to its GEMV kernel there; not restated");
+    // forward_pass (admm.cpp:31,35)
+    static constexpr int FWD_U = (NU > 1 && NU % 4 == 0) ? PLAN_SEQ : (NU == 1 ? plan_vec(NX) : plan_novec(NX));
+    static constexpr int FWD_XA = (NX % 4 == 0) ? PLAN_SEQ : plan_novec(NX);
+    static constexpr int FWD_XB = (NX % 4 == 0) ? PLAN_SEQ : plan_novec(NU);
+    // update_linear_cost terminal term (admm.cpp:83)
+    static constexpr int TERM = plan_vec(NX);
+    // backward_pass_grad (admm.cpp:19-20)
+    static constexpr int BWD_TMP = plan_vec(NX);
+    static constexpr int BWD_D = (NU > 1 && NU % 4 == 0) ? PLAN_SEQ : plan_novec(NU);
+    static constexpr int BWD_PA = (NU == 1 && NX % 4 == 0) ? PLAN_SEQ : plan_novec(NX);
+    static constexpr int BWD_PK = plan_vec(NU);
+};
+
+template <int NX, int NU, int N, bool EXACT>
+__global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P)
+{
+    using PL = RowPlans<NX, NU>;
+    const int lane = threadIdx.x;
+    const int r16 = lane & 15;
+    const int inst = blockIdx.x * 4 + (lane >> 4);
+    const bool valid = inst < P.batch;
+    const bool is_x = r16 < NX;
+    const bool is_u = (r16 >= NX) && (r16 < NX + NU);
+    const float rho = P.rho;
+
+    // ---- box bounds of the whole horizon, shared by the batch: LDS table [N][16] of {lo, hi} ----
+    __shared__ float2 bnd[N * 16];
+    // vnew/znew of the current sweep and the p history live in LDS (lane-linear => conflict free): they are
+    // written once and read once per iteration (sn) or only at the end (ps), so they do not need a VGPR each.
+    __shared__ float sn_lds[N * WAVE];
+    __shared__ float ps_lds[(N - 1) * WAVE];
+    for (int e = lane; e < N * 16; e += WAVE) bnd[e] = reinterpret_cast<const float2 *>(P.bounds)[e];
+    __syncthreads();
+    float *sn = sn_lds + lane;   // sn[i * WAVE]
+    float *ps = ps_lds + lane;   // ps[i * WAVE]
+
+    // ---- gain rows of this lane -----------------------------------------------------------------
+    float M1[NX], M2[NU], M3[NX], M45[NU];
+    {
+        const float *m = P.mats + r16;
+#pragma unroll
+        for (int k = 0; k < NX; k++) M1[k] = m[(k) * 16];
+#pragma unroll
+        for (int k = 0; k < NU; k++) M2[k] = m[(NX + k) * 16];
+#pragma unroll
+        for (int k = 0; k < NX; k++) M3[k] = m[(NX + NU + k) * 16];
+#pragma unroll
+        for (int k = 0; k < NU; k++) M45[k] = m[(2 * NX + NU + k) * 16];
+    }
+
+    // ---- per-instance state, all in registers --------------------------------------------------------
+    //   a[i]  : g_i (x rows) | y_i (u rows)           duals
+    //   b[i]  : v_i          | z_i                    previous slack
+    //   c[i]  : -(Xref_i.*Q) | d_i                    reference cost term | Riccati feed-forward
+    //   sn[i] : vnew_i       | znew_i                 current slack                     (LDS)
+    //   ps[i] : p_i          | -                      Riccati cost-to-go gradient, live-out only (LDS)
+    float a[N], b[N], c[N];
+    const size_t rowbase = ((size_t)inst * N) * 16 + r16;
+    int wstart = 0;
+    if (P.xref_mode == 1 && valid) wstart = P.xref_start[inst];
+    const float *xref_p = P.xref + (size_t)inst * P.xref_inst_stride + r16;
+    const bool cold = P.cold_start != 0;
+    const bool zdual = cold || (P.duals_zero != 0);
+    float xrN = 0.f; // Xref_{N-1}(r)
+    {
+        const float qrow = P.mats[(2 * NX + 2 * NU) * 16 + r16]; // Q(r) on x rows, 0 elsewhere
+#pragma unroll
+        for (int i = 0; i < N; i++)
+        {
+            float xr;
+            if (P.xref_mode == 1)
+            {
+                int row = wstart + i;
+                row = row < P.table_rows ? row : P.table_rows - 1;
+                xr = P.xref_table[(size_t)row * 16 + r16];
+            }
+            else
+                xr = xref_p[(size_t)i * 16];
+            const float pd = cold ? 0.f : P.pd[rowbase + (size_t)i * 16];
+            c[i] = is_x ? -(xr * qrow) : pd;       // admm.cpp:81  q(i,j) = -(Xref(i,j) * Q(i))
+            if (i < N - 1) ps[i * WAVE] = is_x ? pd : 0.f;
+            b[i] = cold ? 0.f : P.vz[rowbase + (size_t)i * 16];
+            a[i] = zdual ? 0.f : P.gy[rowbase + (size_t)i * 16];
+            sn[i * WAVE] = 0.f;
+            if (i == N - 1) xrN = xr;
+        }
+    }
+    const float x0 = P.xu[rowbase]; // x.col(0) on x rows (u rows hold stale u_0, never used as x)
+
+    // -(Xref_{N-1}^T Pinf): constant during a solve (admm.cpp:83)
+    float pterm;
+    {
+        float PT[NX];
+#pragma unroll
+        for (int k = 0; k < NX; k++) PT[k] = P.mats[(2 * NX + 2 * NU + 1 + k) * 16 + r16]; // Pinf(k, r)
+        if constexpr (EXACT)
+        {
+            float t[NX];
+            dpp_products<0, NX>(t, xrN, PT);
+            pterm = -reduce<PL::TERM>(t);
+        }
+        else
+            pterm = -dpp_fma_dot<0, NX>(xrN, PT);
+    }
+
+    int st = TINY_STATUS_UNSOLVED_, itn = 1; // admm.cpp:114-115
+    float r_ps = 0.f, r_pi = 0.f, r_ds = 0.f, r_di = 0.f;
+    if (valid)
+    {
+        r_ps = P.res[4 * inst + 0]; r_pi = P.res[4 * inst + 1];
+        r_ds = P.res[4 * inst + 2]; r_di = P.res[4 * inst + 3];
+    }
+    float pN = 0.f; // p_{N-1} of the last executed forward sweep (x rows)
+    float *xu_out = P.xu + rowbase;
+
+    // u_i and x_{i+1} from s = x_i (x rows); returns the stacked [x_i ; u_i] in sv
+    auto lqr = [&](float s, float ci, float &sv, float &xn) {
+        if constexpr (EXACT)
+        {
+            float t[NX];
+            dpp_products<0, NX>(t, s, M1);
+            float acc;
+            if constexpr (PL::FWD_U == PL::FWD_XA) acc = reduce<PL::FWD_XA>(t);
+            else acc = is_x ? reduce<PL::FWD_XA>(t) : reduce<PL::FWD_U>(t);
+            const float un = (-acc) - ci;                 // u = -Kinf*x - d          (admm.cpp:31)
+            float t2[NU];
+            dpp_products<NX, NU>(t2, un, M2);
+            xn = acc + reduce<PL::FWD_XB>(t2);            // x' = Adyn*x + Bdyn*u     (admm.cpp:35)
+            sv = is_u ? un : s;
+        }
+        else
+        {
+            float acc = dpp_fma_dot<0, NX>(s, M1);        // u rows carry -Kinf
+            const float un = acc - ci;
+            dpp_fma_acc<NX, NU>(acc, un, M2);
+            xn = acc;
+            sv = is_u ? un : s;
+        }
+    };
+
+    bool active = valid && (P.max_iter > 0);
+    for (int it = 0; it < P.max_iter; ++it)
+    {
+        if (!__any(active)) break;
+        const bool last_iter = (it == P.max_iter - 1);
+        if (active)
+        {
+            // ---------------- forward sweep: forward_pass + update_slack + update_dual + residual maxima ----------------
+            float s = x0, pri = 0.f, dua = 0.f;
+            float2 lh = bnd[r16];
+#pragma unroll
+            for (int i = 0; i < N; i++)
+            {
+                const float2 lh_next = bnd[(i + 1 < N ? i + 1 : i) * 16 + r16]; // LDS read one step ahead
+                float sv, xn = 0.f;
+                if (i < N - 1) lqr(s, c[i], sv, xn);
+                else sv = is_x ? s : 0.f;
+                float t = sv + a[i];                       // admm.cpp:47-48
+                // admm.cpp:51-60: min(hi, max(lo, t)).  The host stores lo := min(lo, hi), which makes the median
+                // identical to that expression for every t (and +-inf where a bound is disabled).
+                t = __builtin_amdgcn_fmed3f(t, lh.x, lh.y);
+                a[i] = (a[i] + sv) - t;                    // admm.cpp:69-70
+                pri = fmaxf(pri, fabsf(sv - t));           // admm.cpp:95,97
+                dua = fmaxf(dua, fabsf(b[i] - t));         // admm.cpp:96,98
+                sn[i * WAVE] = t;
+                if (last_iter) xu_out[(size_t)i * 16] = sv; // x,u of an instance that exhausts max_iter
+                s = xn;
+                lh = lh_next;
+                __builtin_amdgcn_sched_barrier(0); // keep the steps apart (VGPR pressure)
+            }
+            {
+                const float t1 = sn[(N - 1) * WAVE] - a[N - 1];
+                if constexpr (EXACT) pN = pterm - rho * t1; // admm.cpp:83-84
+                else pN = __builtin_fmaf(-rho, t1, pterm);
+            }
+            // ---------------- termination_condition (admm.cpp:91-109) ----------------
+            const float pri_x = row_max(is_x ? pri : 0.f), dua_x = row_max(is_x ? dua : 0.f);
+            const float pri_u = row_max(is_u ? pri : 0.f), dua_u = row_max(is_u ? dua : 0.f);
+            itn = it + 1;
+            bool conv = false;
+            if ((it + 1) % P.check_termination == 0)
+            {
+                r_ps = pri_x; r_ds = dua_x * rho; r_pi = pri_u; r_di = dua_u * rho;
+                conv = (r_ps < P.abs_pri_tol) && (r_pi < P.abs_pri_tol) && (r_ds < P.abs_dua_tol) && (r_di < P.abs_dua_tol);
+            }
+            if (conv)
+            {
+                st = TINY_STATUS_SOLVED_;
+                active = false;
+            }
+            else
+            {
+                // ---------------- backward sweep: v=vnew, z=znew, linear cost, backward_pass_grad ----------------
+                float p = pN;
+                b[N - 1] = sn[(N - 1) * WAVE];
+                float sn_pref = sn[(N - 2) * WAVE];
+#pragma unroll
+                for (int i = N - 2; i >= 0; i--)
+                {
+                    const float sni = sn_pref;
+                    sn_pref = sn[(i > 0 ? i - 1 : 0) * WAVE]; // LDS read one step ahead
+                    const float t1 = sni - a[i];
+                    const float cq = is_x ? c[i] : 0.f;
+                    float pn, dd;
+                    if constexpr (EXACT)
+                    {
+                        const float lin = cq - rho * t1;   // x rows: q_i (admm.cpp:81-82) | u rows: r_i (admm.cpp:80)
+                        float t[NX];
+                        dpp_products<0, NX>(t, p, M3);
+                        float dot;
+                        if constexpr (PL::BWD_PA == PL::BWD_TMP) dot = reduce<PL::BWD_PA>(t);
+                        else dot = is_x ? reduce<PL::BWD_PA>(t) : reduce<PL::BWD_TMP>(t);
+                        const float wv = lin + dot;        // q + AmBKt*p  |  Bdyn^T*p + r
+                        float tk[NU], td[NU];
+                        dpp_products<NX, NU>(tk, lin, M45); // Kinf^T * r
+                        dpp_products<NX, NU>(td, wv, M45);  // Quu_inv * (Bdyn^T p + r)
+                        pn = wv - reduce<PL::BWD_PK>(tk);  // admm.cpp:20
+                        dd = reduce<PL::BWD_D>(td);        // admm.cpp:19
+                    }
+                    else
+                    {
+                        float acc = __builtin_fmaf(-rho, t1, cq);
+                        const float lin = acc;
+                        dpp_fma_acc<0, NX>(acc, p, M3);
+                        dd = dpp_fma_dot<NX, NU>(acc, M45); // u rows: Quu_inv
+                        dpp_fma_acc<NX, NU>(acc, lin, M45); // x rows: -Kinf^T
+                        pn = acc;
+                    }
+                    c[i] = is_u ? dd : c[i];
+                    b[i] = sni;                            // admm.cpp:141-142
+                    ps[i * WAVE] = pn;
+                    p = pn;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+
+    if (P.max_iter <= 0) // tiny_solve only sets status and iter (admm.cpp:114-117,151)
+    {
+        if (valid && r16 == 0)
+        {
+            P.status[inst] = TINY_STATUS_UNSOLVED_;
+            P.iter[inst] = 1;
+            atomicAdd(P.n_unsolved, 1);
+        }
+        return;
+    }
+
+    // ---------------- live-out: every work array written once ----------------
+    if (valid)
+    {
+        const bool solved = (st == TINY_STATUS_SOLVED_);
+        float s = x0;
+#pragma unroll
+        for (int i = 0; i < N; i++)
+        {
+            const size_t o = rowbase + (size_t)i * 16;
+            // x,u of a converged instance: regenerated from its frozen d by the same instruction sequence
+            float sv, xn = 0.f;
+            if (i < N - 1) lqr(s, c[i], sv, xn);
+            else sv = is_x ? s : 0.f;
+            if (solved) P.xu[o] = sv;
+            s = xn;
+            const float sni = sn[i * WAVE];
+            const float t1 = sni - a[i];
+            const float cq = is_x ? c[i] : 0.f;
+            float lin;
+            if constexpr (EXACT) lin = cq - rho * t1;
+            else lin = __builtin_fmaf(-rho, t1, cq);
+            P.qr[o] = (i < N - 1 || is_x) ? lin : 0.f;
+            // p.col(N-1) is rewritten by every forward sweep (admm.cpp:83-84), the other columns by the backward sweeps
+            P.pd[o] = (i < N - 1) ? (is_x ? ps[(i < N - 1 ? i : 0) * WAVE] : c[i]) : (is_x ? pN : 0.f);
+            P.vz[o] = b[i];
+            P.vzn[o] = sni;
+            P.gy[o] = a[i];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (r16 == 0)
+        {
+            P.res[4 * inst + 0] = r_ps; P.res[4 * inst + 1] = r_pi;
+            P.res[4 * inst + 2] = r_ds; P.res[4 * inst + 3] = r_di;
+            P.status[inst] = st;
+            P.iter[inst] = itn;
+            if (!solved) atomicAdd(P.n_unsolved, 1);
+        }
+    }
+}
+
+bool rowlane_supported(int nx, int nu, int N)
+{
+#define TINY_ROWLANE_CHECK(NX, NU, NN) \
+    if (nx == NX && nu == NU && N == NN) return true;
+    TINY_FOR_EACH_ROWLANE(TINY_ROWLANE_CHECK)
+    return false;
+}
+
+hipError_t launch_admm_rowlane(int nx, int nu, int N, bool exact, const RowParams &P, hipStream_t stream)
+{
+    const int nblocks = (P.batch + 3) / 4;
+#define TINY_ROWLANE_DISPATCH(NX, NU, NN)                                                                   \
+    if (nx == NX && nu == NU && N == NN)                                                                    \
+    {                                                                                                       \
+        if (exact) hipLaunchKernelGGL((admm_rowlane_kernel<NX, NU, NN, true>), dim3(nblocks), dim3(WAVE), 0, stream, P);  \
+        else hipLaunchKernelGGL((admm_rowlane_kernel<NX, NU, NN, false>), dim3(nblocks), dim3(WAVE), 0, stream, P); \
+        return hipGetLastError();                                                                           \
+    }
+    TINY_FOR_EACH_ROWLANE(TINY_ROWLANE_DISPATCH)
+    return hipErrorInvalidValue;
+}
+
+} // namespace tinympc

@@ -1,15 +1,17 @@
 // tinympc_batch.hip — host side of the C-ABI declared in include/tinympc_batch.h:
-// device-resident batched workspace, layout conversion kernels, MFMA operand packing and
-// kernel dispatch.  The solver kernels live in admm_stream.hip / admm_resident.hip.
+// device-resident batched workspace, layout conversion kernels, gain packing and kernel dispatch.
+// The solver kernels live in admm_rowlane.hip (state on chip) and admm_stream.hip (state in HBM).
 //
 // There is deliberately NO CPU fallback in this library: every entry point that computes
 // launches a HIP kernel and reports HIP failures as TINY_BATCH_EHIP.
 #include "../../include/tinympc_batch.h"
 #include "tinympc_internal.h"
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -37,63 +39,98 @@ int fail(int code, const char *fmt, ...)
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) return fail(TINY_BATCH_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
-
+#define TRY(expr)                 \
+    do                            \
+    {                             \
+        int rc_ = (expr);         \
+        if (rc_) return rc_;      \
+    } while (0)
 #define CHECK_TB(tb) \
     if (!(tb)) return fail(TINY_BATCH_EINVAL, "%s: NULL TinyBatch handle", __func__)
 #define CHECK_PTR(p) \
     if (!(p)) return fail(TINY_BATCH_EINVAL, "%s: NULL pointer argument '%s'", __func__, #p)
 
+enum { LAYOUT_TILE = 0, LAYOUT_ROW = 1 };
+enum { VAR_AUTO = 0, VAR_STREAM = 1, VAR_ROW_EXACT = 2, VAR_ROW_FAST = 3 };
+
 // ---------------------------------------------------------------------------------------------
-// layout conversion: host-visible [B][steps][dim]  <->  tile layout [ntiles][tsteps][64][NC]
+// Element addressing of the two device layouts.  `fam` 0 = state-type (nx rows, N steps),
+// 1 = input-type (nu rows, N-1 steps).
+//   TILE (admm_stream.hip):  x-family [ntiles][N][64][NXC], u-family [ntiles][N-1][64][NUC]
+//   ROW  (admm_rowlane.hip): pair array [batch_pad4][N][16], rows [0,nx) state member, [nx,nx+nu) input member
 // ---------------------------------------------------------------------------------------------
-// dst tile array gets steps [step0, step0+nsteps) from src ([Bsrc][nsteps][dim]; Bsrc==1 => shared).
-__global__ void pack_kernel(const float *__restrict__ src, float *__restrict__ dst, int batch, int shared, int dim,
-                            int NC, int ntiles_dst, int tsteps, int step0, int nsteps)
+struct Geo
 {
-    const long long total = (long long)ntiles_dst * nsteps * WAVE * NC;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x)
+    int nx, nu, N, NXC, NUC;
+};
+
+__device__ __forceinline__ long long idx_tile(const Geo g, int fam, int b, int step, int row)
+{
+    const int tile = b / TILE, c = b % TILE, lane = (row & 3) * 16 + c, ch = row >> 2;
+    const int steps = fam ? g.N - 1 : g.N, NC = fam ? g.NUC : g.NXC;
+    return (((long long)tile * steps + step) * WAVE + lane) * NC + ch;
+}
+__device__ __forceinline__ long long idx_row(const Geo g, int fam, int b, int step, int row)
+{
+    return ((long long)b * g.N + step) * 16 + (fam ? g.nx + row : row);
+}
+__device__ __forceinline__ long long idx_of(int layout, const Geo g, int fam, int b, int step, int row)
+{
+    return layout == LAYOUT_ROW ? idx_row(g, fam, b, step, row) : idx_tile(g, fam, b, step, row);
+}
+
+// host-layout src [cnt][nsteps][dim] (cnt = 1: shared by all instances)  ->  device layout, steps [step0, step0+nsteps)
+// of instances [0, nb).  Rows/instances beyond the source are left untouched (they were zeroed at allocation).
+__global__ void pack_kernel(const float *__restrict__ src, float *__restrict__ dst, int layout, Geo g, int fam, int nb,
+                            int shared, int step0, int nsteps)
+{
+    const int dim = fam ? g.nu : g.nx;
+    const long long total = (long long)nb * nsteps * dim;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x)
     {
-        int ch = (int)(e % NC);
-        long long t = e / NC;
-        int lane = (int)(t % WAVE); t /= WAVE;
-        int s = (int)(t % nsteps);
-        int tile = (int)(t / nsteps);
-        int b = tile * TILE + (lane & 15);
-        int row = 4 * ch + (lane >> 4);
-        float val = 0.f;
-        if (row < dim && (shared || b < batch))
-            val = src[((long long)(shared ? 0 : b) * nsteps + s) * dim + row];
-        dst[(((long long)tile * tsteps + step0 + s) * WAVE + lane) * NC + ch] = val;
+        const int row = (int)(e % dim);
+        const long long t = e / dim;
+        const int s = (int)(t % nsteps), b = (int)(t / nsteps);
+        dst[idx_of(layout, g, fam, b, step0 + s, row)] = src[((long long)(shared ? 0 : b) * nsteps + s) * dim + row];
     }
 }
 
-__global__ void unpack_kernel(const float *__restrict__ src, float *__restrict__ dst, int batch, int dim, int NC,
-                              int tsteps, int step0, int nsteps)
+__global__ void unpack_kernel(const float *__restrict__ src, float *__restrict__ dst, int layout, Geo g, int fam, int nb,
+                              int step0, int nsteps)
 {
-    const long long total = (long long)batch * nsteps * dim;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x)
+    const int dim = fam ? g.nu : g.nx;
+    const long long total = (long long)nb * nsteps * dim;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x)
     {
-        int row = (int)(e % dim);
-        long long t = e / dim;
-        int s = (int)(t % nsteps);
-        int b = (int)(t / nsteps);
-        int tile = b / TILE, c = b % TILE;
-        int lane = (row & 3) * 16 + c, ch = row >> 2;
-        dst[e] = src[(((long long)tile * tsteps + step0 + s) * WAVE + lane) * NC + ch];
+        const int row = (int)(e % dim);
+        const long long t = e / dim;
+        const int s = (int)(t % nsteps), b = (int)(t / nsteps);
+        dst[e] = src[idx_of(layout, g, fam, b, step0 + s, row)];
+    }
+}
+
+// zero steps [step0, step0+nsteps) of one member of a device array
+__global__ void zero_kernel(float *__restrict__ dst, int layout, Geo g, int fam, int nb, int step0, int nsteps)
+{
+    const int dim = fam ? g.nu : g.nx;
+    const long long total = (long long)nb * nsteps * dim;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x)
+    {
+        const int row = (int)(e % dim);
+        const long long t = e / dim;
+        dst[idx_of(layout, g, fam, (int)(t / nsteps), step0 + (int)(t % nsteps), row)] = 0.f;
     }
 }
 
 // x0 <- Adyn*x0 + Bdyn*u.col(0)   (quadrotor_hovering.cpp:110-111), and x.col(0) <- x0 (:95).
 // One thread per instance; matrices column-major in global memory (tiny, cache resident).
-__global__ void plant_step_kernel(float *__restrict__ x0buf, float *__restrict__ xtile, const float *__restrict__ utile,
+__global__ void plant_step_kernel(float *__restrict__ x0buf, float *__restrict__ xarr, const float *__restrict__ uarr,
                                   const float *__restrict__ A, const float *__restrict__ Bm, int *__restrict__ wstart,
-                                  int window_advance, int batch, int nx, int nu, int NXC, int NUC, int N)
+                                  int window_advance, int batch, int layout, Geo g)
 {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
-    int tile = b / TILE, c = b % TILE;
+    const int nx = g.nx, nu = g.nu;
     const float *x0 = x0buf + (long long)b * nx;
     float xn[64];
     for (int i = 0; i < nx; i++)
@@ -101,37 +138,39 @@ __global__ void plant_step_kernel(float *__restrict__ x0buf, float *__restrict__
         float acc = 0.f;
         for (int k = 0; k < nx; k++) acc += A[k * nx + i] * x0[k];
         float acc2 = 0.f;
-        for (int m = 0; m < nu; m++)
-        {
-            float um = utile[(((long long)tile * (N - 1) + 0) * WAVE + ((m & 3) * 16 + c)) * NUC + (m >> 2)];
-            acc2 += Bm[m * nx + i] * um;
-        }
+        for (int m = 0; m < nu; m++) acc2 += Bm[m * nx + i] * uarr[idx_of(layout, g, 1, b, 0, m)];
         xn[i] = acc + acc2;
     }
     for (int i = 0; i < nx; i++)
     {
         x0buf[(long long)b * nx + i] = xn[i];
-        xtile[(((long long)tile * N + 0) * WAVE + ((i & 3) * 16 + c)) * NXC + (i >> 2)] = xn[i];
+        xarr[idx_of(layout, g, 0, b, 0, i)] = xn[i];
     }
     if (wstart && window_advance) wstart[b] += window_advance;
 }
 
-__global__ void gather_u0_kernel(const float *__restrict__ utile, float *__restrict__ u0, int batch, int nu, int NUC, int N)
-{
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= batch * nu) return;
-    int b = e / nu, m = e % nu;
-    int tile = b / TILE, c = b % TILE;
-    u0[e] = utile[(((long long)tile * (N - 1)) * WAVE + ((m & 3) * 16 + c)) * NUC + (m >> 2)];
-}
-
 int grid_for(long long total, int block = 256)
 {
-    long long g = (total + block - 1) / block;
-    if (g > 8192) g = 8192;
-    if (g < 1) g = 1;
-    return (int)g;
+    long long gsz = (total + block - 1) / block;
+    if (gsz > 8192) gsz = 8192;
+    if (gsz < 1) gsz = 1;
+    return (int)gsz;
 }
+
+// pair index of each work array in the ROW layout: x,u | q,r | p,d | v,z | vnew,znew | g,y
+const int kPairOf[TINY_ARR_COUNT] = {0, 0, 1, 1, 2, 2, 3, 4, 3, 4, 5, 5};
+bool is_xfam(int id)
+{
+    return id == TINY_ARR_X || id == TINY_ARR_Q || id == TINY_ARR_P || id == TINY_ARR_V || id == TINY_ARR_VNEW ||
+           id == TINY_ARR_G;
+}
+
+struct InputArr // canonical copy of a caller-provided input, host layout [cnt][steps][dim] on the device
+{
+    float *dev = nullptr;
+    bool shared = true, set = false;
+    std::vector<float> host; // kept only when shared (small)
+};
 
 } // namespace
 
@@ -139,33 +178,40 @@ int grid_for(long long total, int block = 256)
 struct TinyBatch
 {
     int nx = 0, nu = 0, N = 0, batch = 0, device = 0;
-    int NXC = 0, NUC = 0, ntiles = 0;
+    int NXC = 0, NUC = 0, ntiles = 0, bpad4 = 0;
+    bool row_dims_ok = false, tile_dims_ok = false;
     hipStream_t stream = nullptr;
     // problem class
-    bool have_cache = false, have_dyn = false, have_settings = false, operands_dirty = true;
+    bool have_cache = false, have_dyn = false, have_settings = false, gains_dirty = true;
     float rho = 0.f;
     std::vector<float> Kinf, Pinf, Quu_inv, AmBKt, Adyn, Bdyn, Q;
     float abs_pri_tol = 0.f, abs_dua_tol = 0.f;
     int max_iter = 0, check_termination = 1, en_state_bound = 0, en_input_bound = 0;
-    // device memory
-    float *arr[TINY_ARR_COUNT] = {};     // tile layout
-    float *xmin = nullptr, *xmax = nullptr, *umin = nullptr, *umax = nullptr, *xref = nullptr;
-    bool xb_shared[2] = {true, true}, ub_shared[2] = {true, true}, xref_shared = true;
-    size_t xfam_floats = 0, ufam_floats = 0; // per full-batch tile array
-    float *xref_table = nullptr;
+    // work arrays: exactly one layout is allocated at a time
+    int layout = LAYOUT_TILE;
+    float *arr[TINY_ARR_COUNT] = {}; // TILE
+    float *pair[6] = {};             // ROW
+    size_t xfam_floats = 0, ufam_floats = 0, pair_floats = 0;
+    // caller inputs (canonical) and their per-layout derived forms
+    InputArr in_xref, in_bnd[4]; // bnd: xmin, xmax, umin, umax
+    bool derived_dirty[2] = {true, true};
+    float *t_xref = nullptr, *t_bnd[4] = {};              // TILE derived
+    float *r_xref = nullptr, *r_bounds = nullptr;         // ROW derived
+    float *tab_tile = nullptr, *tab_row = nullptr;        // trajectory table in both forms
     int table_rows = 0;
     int *xref_start = nullptr;
     int xref_mode = 0;
     float *res = nullptr;
     int *status = nullptr, *iter = nullptr, *n_unsolved = nullptr;
-    float *opnd = nullptr, *qvec = nullptr;
-    float *dA = nullptr, *dB = nullptr; // column-major copies for the plant step
-    float *x0buf = nullptr;             // [B][nx] host-layout current state (closed loop)
-    float *staging = nullptr;           // host-layout staging for pack/unpack
+    float *opnd = nullptr, *qvec = nullptr;               // TILE gains (MFMA operands)
+    float *mats_exact = nullptr, *mats_fast = nullptr;    // ROW gains
+    float *dA = nullptr, *dB = nullptr;                   // column-major copies for the plant step
+    float *x0buf = nullptr;                               // [B][nx] current state (closed loop)
+    float *staging = nullptr;                             // host-layout staging
     size_t staging_floats = 0;
     bool duals_zero_pending = false;
-    bool cold_pending = false; // reset_workspace() folded into the next solve (d,v,z,y,g read as zero)
-    int variant = 0;
+    bool cold_pending = false;
+    int variant = VAR_AUTO;
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -175,11 +221,7 @@ struct TinyBatch
 namespace
 {
 
-bool is_xfam(int id)
-{
-    return id == TINY_ARR_X || id == TINY_ARR_Q || id == TINY_ARR_P || id == TINY_ARR_V || id == TINY_ARR_VNEW ||
-           id == TINY_ARR_G;
-}
+Geo geo(const TinyBatch *tb) { return Geo{tb->nx, tb->nu, tb->N, tb->NXC, tb->NUC}; }
 
 int set_device(TinyBatch *tb)
 {
@@ -187,64 +229,155 @@ int set_device(TinyBatch *tb)
     return 0;
 }
 
-// upload a host-layout array ([Bsrc][nsteps][dim]) into steps [step0, step0+nsteps) of a tile array
-int upload_packed(TinyBatch *tb, const float *host, float *dst, bool xfam, bool shared, int step0, int nsteps)
+int dev_alloc_zero(float **p, size_t nfloats)
 {
-    const int dim = xfam ? tb->nx : tb->nu, NC = xfam ? tb->NXC : tb->NUC;
-    const int tsteps = xfam ? tb->N : tb->N - 1;
-    const size_t n = (size_t)(shared ? 1 : tb->batch) * nsteps * dim;
-    if (n > tb->staging_floats) return fail(TINY_BATCH_EINVAL, "internal: staging too small");
-    HIP_TRY(hipMemcpyAsync(tb->staging, host, n * sizeof(float), hipMemcpyHostToDevice, tb->stream));
-    const int ntd = shared ? 1 : tb->ntiles;
-    const long long total = (long long)ntd * nsteps * WAVE * NC;
-    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(256), 0, tb->stream, tb->staging, dst, tb->batch,
-                       shared ? 1 : 0, dim, NC, ntd, tsteps, step0, nsteps);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(tb->stream)); // staging and `host` are reusable on return
+    HIP_TRY(hipMalloc((void **)p, nfloats * sizeof(float)));
+    HIP_TRY(hipMemset(*p, 0, nfloats * sizeof(float)));
     return 0;
 }
 
-int download_unpacked(TinyBatch *tb, const float *src, float *host, bool xfam, int step0, int nsteps)
+float *work_ptr(TinyBatch *tb, int id) { return tb->layout == LAYOUT_ROW ? tb->pair[kPairOf[id]] : tb->arr[id]; }
+
+int alloc_layout(TinyBatch *tb, int layout)
 {
-    const int dim = xfam ? tb->nx : tb->nu, NC = xfam ? tb->NXC : tb->NUC;
-    const int tsteps = xfam ? tb->N : tb->N - 1;
-    const size_t n = (size_t)tb->batch * nsteps * dim;
-    if (n > tb->staging_floats) return fail(TINY_BATCH_EINVAL, "internal: staging too small");
-    hipLaunchKernelGGL(unpack_kernel, dim3(grid_for((long long)n)), dim3(256), 0, tb->stream, src, tb->staging,
-                       tb->batch, dim, NC, tsteps, step0, nsteps);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(host, tb->staging, n * sizeof(float), hipMemcpyDeviceToHost, tb->stream));
-    HIP_TRY(hipStreamSynchronize(tb->stream));
+    if (layout == LAYOUT_ROW)
+    {
+        for (int p = 0; p < 6; p++)
+            if (!tb->pair[p]) TRY(dev_alloc_zero(&tb->pair[p], tb->pair_floats));
+    }
+    else
+    {
+        for (int id = 0; id < TINY_ARR_COUNT; id++)
+            if (!tb->arr[id]) TRY(dev_alloc_zero(&tb->arr[id], is_xfam(id) ? tb->xfam_floats : tb->ufam_floats));
+    }
     return 0;
 }
 
-// Materialise a pending reset_dual_variables() (needed before anything other than a solve looks at y/g).
+void free_layout(TinyBatch *tb, int layout)
+{
+    if (layout == LAYOUT_ROW)
+        for (int p = 0; p < 6; p++) { (void)hipFree(tb->pair[p]); tb->pair[p] = nullptr; }
+    else
+        for (int id = 0; id < TINY_ARR_COUNT; id++) { (void)hipFree(tb->arr[id]); tb->arr[id] = nullptr; }
+}
+
+int launch_pack(TinyBatch *tb, const float *src, float *dst, int layout, int fam, int nb, bool shared, int step0, int nsteps)
+{
+    const long long total = (long long)nb * nsteps * (fam ? tb->nu : tb->nx);
+    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(256), 0, tb->stream, src, dst, layout, geo(tb), fam, nb,
+                       shared ? 1 : 0, step0, nsteps);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int launch_unpack(TinyBatch *tb, const float *src, float *dst, int layout, int fam, int nb, int step0, int nsteps)
+{
+    const long long total = (long long)nb * nsteps * (fam ? tb->nu : tb->nx);
+    hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(total)), dim3(256), 0, tb->stream, src, dst, layout, geo(tb), fam, nb,
+                       step0, nsteps);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int launch_zero(TinyBatch *tb, float *dst, int layout, int fam, int step0, int nsteps)
+{
+    const long long total = (long long)tb->batch * nsteps * (fam ? tb->nu : tb->nx);
+    hipLaunchKernelGGL(zero_kernel, dim3(grid_for(total)), dim3(256), 0, tb->stream, dst, layout, geo(tb), fam, tb->batch,
+                       step0, nsteps);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Materialise pending lazy resets (needed before anything other than a solve looks at the arrays).
 int flush_pending(TinyBatch *tb)
 {
     if (tb->cold_pending)
     {
         // every work array reads as zero after reset_workspace(), except x.col(0) which carries x0
         for (int id = 0; id < TINY_ARR_COUNT; id++)
-            if (id != TINY_ARR_X)
-                HIP_TRY(hipMemsetAsync(tb->arr[id], 0, (is_xfam(id) ? tb->xfam_floats : tb->ufam_floats) * sizeof(float), tb->stream));
         {
-            const size_t step_bytes = (size_t)WAVE * tb->NXC * sizeof(float);
-            HIP_TRY(hipMemset2DAsync(tb->arr[TINY_ARR_X] + (size_t)WAVE * tb->NXC, step_bytes * tb->N, 0,
-                                     step_bytes * (tb->N - 1), tb->ntiles, tb->stream));
+            const int fam = is_xfam(id) ? 0 : 1;
+            const int steps = fam ? tb->N - 1 : tb->N;
+            if (id == TINY_ARR_X) TRY(launch_zero(tb, work_ptr(tb, id), tb->layout, 0, 1, tb->N - 1));
+            else TRY(launch_zero(tb, work_ptr(tb, id), tb->layout, fam, 0, steps));
         }
         tb->cold_pending = false;
         tb->duals_zero_pending = false;
     }
     if (tb->duals_zero_pending)
     {
-        HIP_TRY(hipMemsetAsync(tb->arr[TINY_ARR_Y], 0, tb->ufam_floats * sizeof(float), tb->stream));
-        HIP_TRY(hipMemsetAsync(tb->arr[TINY_ARR_G], 0, tb->xfam_floats * sizeof(float), tb->stream));
+        TRY(launch_zero(tb, work_ptr(tb, TINY_ARR_Y), tb->layout, 1, 0, tb->N - 1));
+        TRY(launch_zero(tb, work_ptr(tb, TINY_ARR_G), tb->layout, 0, 0, tb->N));
         tb->duals_zero_pending = false;
     }
     return 0;
 }
 
-// ---- MFMA A-operand packing -----------------------------------------------------------------
+// Move the twelve work arrays to another device layout (through the host-layout staging buffer, on the device).
+int ensure_layout(TinyBatch *tb, int want)
+{
+    if (tb->layout == want) return 0;
+    TRY(flush_pending(tb));
+    const int from = tb->layout;
+    TRY(alloc_layout(tb, want));
+    for (int id = 0; id < TINY_ARR_COUNT; id++)
+    {
+        const int fam = is_xfam(id) ? 0 : 1, steps = fam ? tb->N - 1 : tb->N;
+        const float *src = from == LAYOUT_ROW ? tb->pair[kPairOf[id]] : tb->arr[id];
+        float *dst = want == LAYOUT_ROW ? tb->pair[kPairOf[id]] : tb->arr[id];
+        TRY(launch_unpack(tb, src, tb->staging, from, fam, tb->batch, 0, steps));
+        TRY(launch_pack(tb, tb->staging, dst, want, fam, tb->batch, false, 0, steps));
+    }
+    HIP_TRY(hipStreamSynchronize(tb->stream));
+    free_layout(tb, from);
+    tb->layout = want;
+    return 0;
+}
+
+// upload a host array ([batch][nsteps][dim]) into steps [step0, ...) of a work array of the current layout
+int upload_work(TinyBatch *tb, const float *host, int id, int step0, int nsteps)
+{
+    const int fam = is_xfam(id) ? 0 : 1;
+    const size_t n = (size_t)tb->batch * nsteps * (fam ? tb->nu : tb->nx);
+    if (n > tb->staging_floats) return fail(TINY_BATCH_EINVAL, "internal: staging too small");
+    HIP_TRY(hipMemcpyAsync(tb->staging, host, n * sizeof(float), hipMemcpyHostToDevice, tb->stream));
+    TRY(launch_pack(tb, tb->staging, work_ptr(tb, id), tb->layout, fam, tb->batch, false, step0, nsteps));
+    HIP_TRY(hipStreamSynchronize(tb->stream)); // staging and `host` are reusable on return
+    return 0;
+}
+
+int download_work(TinyBatch *tb, int id, float *host, int step0, int nsteps)
+{
+    const int fam = is_xfam(id) ? 0 : 1;
+    const size_t n = (size_t)tb->batch * nsteps * (fam ? tb->nu : tb->nx);
+    if (n > tb->staging_floats) return fail(TINY_BATCH_EINVAL, "internal: staging too small");
+    TRY(launch_unpack(tb, work_ptr(tb, id), tb->staging, tb->layout, fam, tb->batch, step0, nsteps));
+    HIP_TRY(hipMemcpyAsync(host, tb->staging, n * sizeof(float), hipMemcpyDeviceToHost, tb->stream));
+    HIP_TRY(hipStreamSynchronize(tb->stream));
+    return 0;
+}
+
+int store_input(TinyBatch *tb, InputArr &in, const float *host, bool shared, int steps, int dim)
+{
+    const size_t n = (size_t)(shared ? 1 : tb->batch) * steps * dim;
+    if (in.dev && in.shared != shared) { (void)hipFree(in.dev); in.dev = nullptr; }
+    if (!in.dev) HIP_TRY(hipMalloc((void **)&in.dev, n * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(in.dev, host, n * sizeof(float), hipMemcpyHostToDevice, tb->stream));
+    HIP_TRY(hipStreamSynchronize(tb->stream));
+    in.shared = shared;
+    in.set = true;
+    if (shared) in.host.assign(host, host + n);
+    else in.host.clear();
+    tb->derived_dirty[0] = tb->derived_dirty[1] = true;
+    return 0;
+}
+
+bool bounds_all_shared(const TinyBatch *tb)
+{
+    for (int k = 0; k < 4; k++)
+        if (tb->in_bnd[k].set && !tb->in_bnd[k].shared) return false;
+    return true;
+}
+
+// ---- gains for the streaming kernel: MFMA A operands ---------------------------------------------
 // Stacked vector s = [x ; u] in chunks of 4 rows; chunk ch, in-chunk row g  <->  x row 4ch+g (ch < NXC)
 // or u row 4(ch-NXC)+g.  For v_mfma_f32_16x16x4_f32 the A operand of lane l is A[i = l&15][k = l>>4];
 // the D row i of output tile t is held by lane group i>>2 in register i&3, which we DEFINE to be
@@ -272,126 +405,254 @@ void pack_one(const TinyBatch *tb, std::vector<float> &out, int t_out, int ch_in
     }
 }
 
-int pack_operands(TinyBatch *tb)
+int upload_vec(TinyBatch *tb, float **dst, const std::vector<float> &v)
+{
+    if (!*dst) HIP_TRY(hipMalloc((void **)dst, v.size() * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice, tb->stream));
+    HIP_TRY(hipStreamSynchronize(tb->stream)); // `v` may be a temporary
+    return 0;
+}
+
+int pack_gains(TinyBatch *tb)
 {
     const int nx = tb->nx, nu = tb->nu, NXC = tb->NXC, NUC = tb->NUC;
-    const int NCH = NXC + NUC, NT = (NCH + 3) / 4, NTX = (NXC + 3) / 4, TU0 = NXC / 4;
     const float *K = tb->Kinf.data(), *Pf = tb->Pinf.data(), *Qi = tb->Quu_inv.data(), *Am = tb->AmBKt.data();
     const float *A = tb->Adyn.data(), *B = tb->Bdyn.data();
-    // column-major accessors
     auto Kat = [&](int m, int k) { return K[k * nu + m]; };
     auto Aat = [&](int j, int k) { return A[k * nx + j]; };
     auto Bat = [&](int j, int m) { return B[m * nx + j]; };
     auto Amat = [&](int j, int k) { return Am[k * nx + j]; };
     auto Qiat = [&](int a, int b) { return Qi[b * nu + a]; };
     auto Pat = [&](int k, int j) { return Pf[j * nx + k]; };
-    std::vector<float> o;
-    // A1: fwd [A ; -K] * x
-    for (int t = 0; t < NT; t++)
-        for (int k = 0; k < NXC; k++)
-            pack_one(tb, o, t, k, [&](RowRef out, RowRef in) {
-                if (in.fam != 0) return 0.f;
-                return out.fam == 0 ? Aat(out.idx, in.idx) : -Kat(out.idx, in.idx);
-            });
-    // A2: fwd [B] * u
-    for (int t = 0; t < NTX; t++)
-        for (int m = 0; m < NUC; m++)
-            pack_one(tb, o, t, NXC + m, [&](RowRef out, RowRef in) {
-                return (out.fam == 0 && in.fam == 1) ? Bat(out.idx, in.idx) : 0.f;
-            });
-    // A3: bwd [AmBKt ; B^T] * p
-    for (int t = 0; t < NT; t++)
-        for (int k = 0; k < NXC; k++)
-            pack_one(tb, o, t, k, [&](RowRef out, RowRef in) {
-                if (in.fam != 0) return 0.f;
-                return out.fam == 0 ? Amat(out.idx, in.idx) : Bat(in.idx, out.idx);
-            });
-    // A4: bwd [-K^T] * r
-    for (int t = 0; t < NTX; t++)
-        for (int m = 0; m < NUC; m++)
-            pack_one(tb, o, t, NXC + m, [&](RowRef out, RowRef in) {
-                return (out.fam == 0 && in.fam == 1) ? -Kat(in.idx, out.idx) : 0.f;
-            });
-    // A5: bwd [Quu_inv] * (B^T p + r), output tiles TU0..NT-1
-    for (int t = TU0; t < NT; t++)
-        for (int m = 0; m < NUC; m++)
-            pack_one(tb, o, t, NXC + m, [&](RowRef out, RowRef in) {
-                return (out.fam == 1 && in.fam == 1) ? Qiat(out.idx, in.idx) : 0.f;
-            });
-    // AP: terminal  p_j = -(sum_k Xref_k Pinf(k,j))
-    for (int t = 0; t < NTX; t++)
-        for (int k = 0; k < NXC; k++)
-            pack_one(tb, o, t, k, [&](RowRef out, RowRef in) {
-                return (out.fam == 0 && in.fam == 0) ? -Pat(in.idx, out.idx) : 0.f;
-            });
-    std::vector<float> qv((size_t)WAVE * NXC, 0.f);
-    for (int l = 0; l < WAVE; l++)
-        for (int ch = 0; ch < NXC; ch++)
+    if (tb->tile_dims_ok)
+    {
+        const int NCH = NXC + NUC, NT = (NCH + 3) / 4, NTX = (NXC + 3) / 4, TU0 = NXC / 4;
+        std::vector<float> o;
+        for (int t = 0; t < NT; t++) // A1: fwd [A ; -K] * x
+            for (int k = 0; k < NXC; k++)
+                pack_one(tb, o, t, k, [&](RowRef out, RowRef in) {
+                    if (in.fam != 0) return 0.f;
+                    return out.fam == 0 ? Aat(out.idx, in.idx) : -Kat(out.idx, in.idx);
+                });
+        for (int t = 0; t < NTX; t++) // A2: fwd [B] * u
+            for (int m = 0; m < NUC; m++)
+                pack_one(tb, o, t, NXC + m, [&](RowRef out, RowRef in) { return (out.fam == 0 && in.fam == 1) ? Bat(out.idx, in.idx) : 0.f; });
+        for (int t = 0; t < NT; t++) // A3: bwd [AmBKt ; B^T] * p
+            for (int k = 0; k < NXC; k++)
+                pack_one(tb, o, t, k, [&](RowRef out, RowRef in) {
+                    if (in.fam != 0) return 0.f;
+                    return out.fam == 0 ? Amat(out.idx, in.idx) : Bat(in.idx, out.idx);
+                });
+        for (int t = 0; t < NTX; t++) // A4: bwd [-K^T] * r
+            for (int m = 0; m < NUC; m++)
+                pack_one(tb, o, t, NXC + m, [&](RowRef out, RowRef in) { return (out.fam == 0 && in.fam == 1) ? -Kat(in.idx, out.idx) : 0.f; });
+        for (int t = TU0; t < NT; t++) // A5: bwd [Quu_inv] * (B^T p + r)
+            for (int m = 0; m < NUC; m++)
+                pack_one(tb, o, t, NXC + m, [&](RowRef out, RowRef in) { return (out.fam == 1 && in.fam == 1) ? Qiat(out.idx, in.idx) : 0.f; });
+        for (int t = 0; t < NTX; t++) // AP: terminal  p_j = -(sum_k Xref_k Pinf(k,j))
+            for (int k = 0; k < NXC; k++)
+                pack_one(tb, o, t, k, [&](RowRef out, RowRef in) { return (out.fam == 0 && in.fam == 0) ? -Pat(in.idx, out.idx) : 0.f; });
+        std::vector<float> qv((size_t)WAVE * NXC, 0.f);
+        for (int l = 0; l < WAVE; l++)
+            for (int ch = 0; ch < NXC; ch++)
+            {
+                int r = 4 * ch + (l >> 4);
+                if (r < nx) qv[(size_t)l * NXC + ch] = tb->Q[r];
+            }
+        TRY(upload_vec(tb, &tb->opnd, o));
+        TRY(upload_vec(tb, &tb->qvec, qv));
+    }
+    if (tb->row_dims_ok)
+    {
+        // ---- gains for the rowlane kernel: [3nx + 2nu + 1][16], entry (reg, r) = the value lane r of a row holds.
+        //   M1[k]  (k<nx): x rows A(r,k)      | u rows  K(m,k)   (exact) / -K(m,k) (fast)
+        //   M2[m]  (m<nu): x rows B(r,m)      | u rows  0
+        //   M3[k]  (k<nx): x rows AmBKt(r,k)  | u rows  B(k,m)          [= Bdyn^T]
+        //   M45[m] (m<nu): x rows K(m,r) (exact) / -K(m,r) (fast)  | u rows  Quu_inv(mr,m)
+        //   Q             : x rows Q(r)
+        //   PT[k]  (k<nx): x rows Pinf(k,r)
+        for (int fast = 0; fast < 2; fast++)
         {
-            int r = 4 * ch + (l >> 4);
-            if (r < nx) qv[(size_t)l * NXC + ch] = tb->Q[r];
+            const float sg = fast ? -1.f : 1.f;
+            const int nreg = 3 * nx + 2 * nu + 1;
+            std::vector<float> m((size_t)nreg * 16, 0.f);
+            for (int r = 0; r < 16; r++)
+            {
+                const bool isx = r < nx, isu = r >= nx && r < nx + nu;
+                const int mr = r - nx;
+                for (int k = 0; k < nx; k++)
+                {
+                    m[(size_t)k * 16 + r] = isx ? Aat(r, k) : (isu ? sg * Kat(mr, k) : 0.f);
+                    m[(size_t)(nx + nu + k) * 16 + r] = isx ? Amat(r, k) : (isu ? Bat(k, mr) : 0.f);
+                    m[(size_t)(2 * nx + 2 * nu + 1 + k) * 16 + r] = isx ? Pat(k, r) : 0.f;
+                }
+                for (int mm = 0; mm < nu; mm++)
+                {
+                    m[(size_t)(nx + mm) * 16 + r] = isx ? Bat(r, mm) : 0.f;
+                    m[(size_t)(2 * nx + nu + mm) * 16 + r] = isx ? sg * Kat(mm, r) : (isu ? Qiat(mr, mm) : 0.f);
+                }
+                m[(size_t)(2 * nx + 2 * nu) * 16 + r] = isx ? tb->Q[r] : 0.f;
+            }
+            TRY(upload_vec(tb, fast ? &tb->mats_fast : &tb->mats_exact, m));
         }
-    if (!tb->opnd) HIP_TRY(hipMalloc(&tb->opnd, o.size() * sizeof(float)));
-    if (!tb->qvec) HIP_TRY(hipMalloc(&tb->qvec, qv.size() * sizeof(float)));
-    if (!tb->dA) HIP_TRY(hipMalloc(&tb->dA, (size_t)nx * nx * sizeof(float)));
-    if (!tb->dB) HIP_TRY(hipMalloc(&tb->dB, (size_t)nx * nu * sizeof(float)));
-    HIP_TRY(hipMemcpyAsync(tb->opnd, o.data(), o.size() * sizeof(float), hipMemcpyHostToDevice, tb->stream));
-    HIP_TRY(hipMemcpyAsync(tb->qvec, qv.data(), qv.size() * sizeof(float), hipMemcpyHostToDevice, tb->stream));
+    }
+    if (!tb->dA) HIP_TRY(hipMalloc((void **)&tb->dA, (size_t)nx * nx * sizeof(float)));
+    if (!tb->dB) HIP_TRY(hipMalloc((void **)&tb->dB, (size_t)nx * nu * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(tb->dA, A, (size_t)nx * nx * sizeof(float), hipMemcpyHostToDevice, tb->stream));
     HIP_TRY(hipMemcpyAsync(tb->dB, B, (size_t)nx * nu * sizeof(float), hipMemcpyHostToDevice, tb->stream));
     HIP_TRY(hipStreamSynchronize(tb->stream));
-    tb->operands_dirty = false;
+    tb->gains_dirty = false;
     return 0;
 }
 
-bool dims_supported(int nxc, int nuc)
+// (re)build the layout-specific forms of the caller's inputs (Xref, bounds)
+int prepare_inputs(TinyBatch *tb, int layout)
 {
-#define TINY_CHECK_DIMS(NXC, NUC) \
-    if (nxc == NXC && nuc == NUC) return true;
-    TINY_FOR_EACH_DIMS(TINY_CHECK_DIMS)
-    return false;
+    if (!tb->derived_dirty[layout]) return 0;
+    const int N = tb->N, nx = tb->nx, nu = tb->nu;
+    if (layout == LAYOUT_TILE)
+    {
+        for (int k = 0; k < 4; k++)
+        {
+            const int fam = k < 2 ? 0 : 1;
+            const size_t nf = fam ? tb->ufam_floats : tb->xfam_floats;
+            if (!tb->t_bnd[k]) TRY(dev_alloc_zero(&tb->t_bnd[k], nf));
+            const InputArr &in = tb->in_bnd[k];
+            if (in.set) // shared inputs fill tile 0 only (tile stride 0 in the kernel)
+                TRY(launch_pack(tb, in.dev, tb->t_bnd[k], LAYOUT_TILE, fam, in.shared ? TILE : tb->batch, in.shared, 0, fam ? N - 1 : N));
+        }
+        if (!tb->t_xref) TRY(dev_alloc_zero(&tb->t_xref, tb->xfam_floats));
+        if (tb->in_xref.set)
+            TRY(launch_pack(tb, tb->in_xref.dev, tb->t_xref, LAYOUT_TILE, 0, tb->in_xref.shared ? TILE : tb->batch, tb->in_xref.shared, 0, N));
+    }
+    else
+    {
+        // bounds table [N][16]{lo,hi}: +-inf where a bound is disabled or the row carries nothing; lo := min(lo, hi)
+        // (min(hi, max(lo, t)) == med3(t, min(lo,hi), hi) for every t, also for the infeasible lo > hi case)
+        const float inf = std::numeric_limits<float>::infinity();
+        std::vector<float> tab((size_t)N * 16 * 2);
+        for (int i = 0; i < N; i++)
+            for (int r = 0; r < 16; r++)
+            {
+                float lo = -inf, hi = inf;
+                if (r < nx && tb->en_state_bound)
+                {
+                    lo = tb->in_bnd[0].set ? tb->in_bnd[0].host[(size_t)i * nx + r] : 0.f;
+                    hi = tb->in_bnd[1].set ? tb->in_bnd[1].host[(size_t)i * nx + r] : 0.f;
+                }
+                else if (r >= nx && r < nx + nu && i < N - 1 && tb->en_input_bound)
+                {
+                    lo = tb->in_bnd[2].set ? tb->in_bnd[2].host[(size_t)i * nu + (r - nx)] : 0.f;
+                    hi = tb->in_bnd[3].set ? tb->in_bnd[3].host[(size_t)i * nu + (r - nx)] : 0.f;
+                }
+                tab[((size_t)i * 16 + r) * 2 + 0] = lo < hi ? lo : hi;
+                tab[((size_t)i * 16 + r) * 2 + 1] = hi;
+            }
+        TRY(upload_vec(tb, &tb->r_bounds, tab));
+        const size_t nf = (size_t)(tb->in_xref.set && !tb->in_xref.shared ? tb->bpad4 : 1) * N * 16;
+        if (tb->r_xref) { (void)hipFree(tb->r_xref); tb->r_xref = nullptr; }
+        TRY(dev_alloc_zero(&tb->r_xref, nf));
+        if (tb->in_xref.set)
+            TRY(launch_pack(tb, tb->in_xref.dev, tb->r_xref, LAYOUT_ROW, 0, tb->in_xref.shared ? 1 : tb->batch, tb->in_xref.shared, 0, N));
+    }
+    HIP_TRY(hipStreamSynchronize(tb->stream));
+    tb->derived_dirty[layout] = false;
+    return 0;
 }
 
-void fill_params(TinyBatch *tb, SolveParams &P)
+int resolve_variant(TinyBatch *tb, int *out)
 {
-    P.nx = tb->nx; P.nu = tb->nu; P.N = tb->N; P.batch = tb->batch; P.ntiles = tb->ntiles;
-    P.rho = tb->rho; P.abs_pri_tol = tb->abs_pri_tol; P.abs_dua_tol = tb->abs_dua_tol;
-    P.max_iter = tb->max_iter; P.check_termination = tb->check_termination;
-    P.en_state_bound = tb->en_state_bound; P.en_input_bound = tb->en_input_bound;
-    P.duals_zero = tb->duals_zero_pending ? 1 : 0;
-    P.cold_start = tb->cold_pending ? 1 : 0;
-    P.xref_mode = tb->xref_mode;
-    P.x = tb->arr[TINY_ARR_X]; P.q = tb->arr[TINY_ARR_Q]; P.p = tb->arr[TINY_ARR_P];
-    P.v = tb->arr[TINY_ARR_V]; P.vnew = tb->arr[TINY_ARR_VNEW]; P.g = tb->arr[TINY_ARR_G];
-    P.u = tb->arr[TINY_ARR_U]; P.r = tb->arr[TINY_ARR_R]; P.d = tb->arr[TINY_ARR_D];
-    P.z = tb->arr[TINY_ARR_Z]; P.znew = tb->arr[TINY_ARR_ZNEW]; P.y = tb->arr[TINY_ARR_Y];
-    P.xmin = tb->xmin; P.xmax = tb->xmax; P.umin = tb->umin; P.umax = tb->umax; P.xref = tb->xref;
-    const long long xt = (long long)tb->N * WAVE * tb->NXC, ut = (long long)(tb->N - 1) * WAVE * tb->NUC;
-    P.xb_tile_stride = (tb->xb_shared[0] && tb->xb_shared[1]) ? 0 : xt;
-    P.ub_tile_stride = (tb->ub_shared[0] && tb->ub_shared[1]) ? 0 : ut;
-    P.xref_tile_stride = tb->xref_shared ? 0 : xt;
-    P.xref_table = tb->xref_table; P.xref_start = tb->xref_start; P.table_rows = tb->table_rows;
-    P.res = tb->res; P.status = tb->status; P.iter = tb->iter; P.n_unsolved = tb->n_unsolved;
-    P.opnd = tb->opnd; P.qvec = tb->qvec;
+    int v = tb->variant;
+    const bool row_ok = tb->row_dims_ok && bounds_all_shared(tb);
+    if (v == VAR_AUTO) v = row_ok ? VAR_ROW_EXACT : VAR_STREAM;
+    if ((v == VAR_ROW_EXACT || v == VAR_ROW_FAST) && !row_ok)
+    {
+        if (tb->row_dims_ok)
+            return fail(TINY_BATCH_EUNSUPPORTED, "the rowlane kernel needs batch-shared bounds; per-instance bounds run on the streaming kernel");
+        return fail(TINY_BATCH_EUNSUPPORTED, "no rowlane kernel instantiation for nx=%d nu=%d N=%d", tb->nx, tb->nu, tb->N);
+    }
+    if (v == VAR_STREAM && !tb->tile_dims_ok)
+        return fail(TINY_BATCH_EUNSUPPORTED, "no streaming kernel instantiation for nx=%d nu=%d", tb->nx, tb->nu);
+    *out = v;
+    return 0;
+}
+
+void update_kname(TinyBatch *tb)
+{
+    int v = 0;
+    char nm[96];
+    const std::string keep = g_err;
+    if (resolve_variant(tb, &v)) { tb->kname = "unsupported"; g_err = keep; return; }
+    if (v == VAR_STREAM) snprintf(nm, sizeof nm, "stream<%d,%d>", tb->NXC, tb->NUC);
+    else snprintf(nm, sizeof nm, "rowlane<%d,%d,%d,%s>", tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT ? "exact" : "fast");
+    tb->kname = nm;
 }
 
 int launch_solve(TinyBatch *tb)
 {
     if (!tb->have_cache || !tb->have_dyn || !tb->have_settings)
         return fail(TINY_BATCH_ENOTREADY, "tiny_batch_solve: set_cache, set_dynamics and set_settings must be called first");
-    if (tb->check_termination <= 0)
-        return fail(TINY_BATCH_EINVAL, "check_termination must be >= 1 (the reference divides by it, admm.cpp:93)");
-    if (set_device(tb)) return TINY_BATCH_EHIP;
-    if (tb->operands_dirty)
-        if (int rc = pack_operands(tb)) return rc;
-    if (tb->max_iter <= 0)
-        if (int rc = flush_pending(tb)) return rc;
-    // a bound array that is per-instance while its partner is shared: expand the shared one
-    SolveParams P;
-    fill_params(tb, P);
+    for (int k = 0; k < 4; k += 2)
+    {
+        const InputArr &lo = tb->in_bnd[k], &hi = tb->in_bnd[k + 1];
+        const bool lo_inst = lo.set && !lo.shared, hi_inst = hi.set && !hi.shared;
+        if (lo_inst != hi_inst && (lo.set || hi.set))
+            return fail(TINY_BATCH_EINVAL, "min and max bounds must both be shared or both be per-instance");
+    }
+    TRY(set_device(tb));
+    int v = 0;
+    TRY(resolve_variant(tb, &v));
+    if (tb->gains_dirty) TRY(pack_gains(tb));
+    const int layout = (v == VAR_STREAM) ? LAYOUT_TILE : LAYOUT_ROW;
+    TRY(ensure_layout(tb, layout));
+    TRY(prepare_inputs(tb, layout));
+    if (tb->max_iter <= 0) TRY(flush_pending(tb));
+    update_kname(tb);
     HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, sizeof(int), tb->stream));
     if (tb->timing) HIP_TRY(hipEventRecord(tb->ev0, tb->stream));
-    hipError_t e = launch_admm_stream(tb->NXC, tb->NUC, P, tb->stream);
+    hipError_t e;
+    if (layout == LAYOUT_TILE)
+    {
+        SolveParams P;
+        P.nx = tb->nx; P.nu = tb->nu; P.N = tb->N; P.batch = tb->batch; P.ntiles = tb->ntiles;
+        P.rho = tb->rho; P.abs_pri_tol = tb->abs_pri_tol; P.abs_dua_tol = tb->abs_dua_tol;
+        P.max_iter = tb->max_iter; P.check_termination = tb->check_termination;
+        P.en_state_bound = tb->en_state_bound; P.en_input_bound = tb->en_input_bound;
+        P.duals_zero = tb->duals_zero_pending ? 1 : 0;
+        P.cold_start = tb->cold_pending ? 1 : 0;
+        P.xref_mode = tb->xref_mode;
+        P.x = tb->arr[TINY_ARR_X]; P.q = tb->arr[TINY_ARR_Q]; P.p = tb->arr[TINY_ARR_P];
+        P.v = tb->arr[TINY_ARR_V]; P.vnew = tb->arr[TINY_ARR_VNEW]; P.g = tb->arr[TINY_ARR_G];
+        P.u = tb->arr[TINY_ARR_U]; P.r = tb->arr[TINY_ARR_R]; P.d = tb->arr[TINY_ARR_D];
+        P.z = tb->arr[TINY_ARR_Z]; P.znew = tb->arr[TINY_ARR_ZNEW]; P.y = tb->arr[TINY_ARR_Y];
+        P.xmin = tb->t_bnd[0]; P.xmax = tb->t_bnd[1]; P.umin = tb->t_bnd[2]; P.umax = tb->t_bnd[3]; P.xref = tb->t_xref;
+        const long long xt = (long long)tb->N * WAVE * tb->NXC, ut = (long long)(tb->N - 1) * WAVE * tb->NUC;
+        P.xb_tile_stride = (tb->in_bnd[0].set && !tb->in_bnd[0].shared) ? xt : 0;
+        P.ub_tile_stride = (tb->in_bnd[2].set && !tb->in_bnd[2].shared) ? ut : 0;
+        P.xref_tile_stride = (tb->in_xref.set && !tb->in_xref.shared) ? xt : 0;
+        P.xref_table = tb->tab_tile; P.xref_start = tb->xref_start; P.table_rows = tb->table_rows;
+        P.res = tb->res; P.status = tb->status; P.iter = tb->iter; P.n_unsolved = tb->n_unsolved;
+        P.opnd = tb->opnd; P.qvec = tb->qvec;
+        e = launch_admm_stream(tb->NXC, tb->NUC, P, tb->stream);
+    }
+    else
+    {
+        RowParams P;
+        P.nx = tb->nx; P.nu = tb->nu; P.N = tb->N; P.batch = tb->batch;
+        P.rho = tb->rho; P.abs_pri_tol = tb->abs_pri_tol; P.abs_dua_tol = tb->abs_dua_tol;
+        P.max_iter = tb->max_iter; P.check_termination = tb->check_termination;
+        P.duals_zero = tb->duals_zero_pending ? 1 : 0;
+        P.cold_start = tb->cold_pending ? 1 : 0;
+        P.xref_mode = tb->xref_mode;
+        P.xu = tb->pair[0]; P.qr = tb->pair[1]; P.pd = tb->pair[2]; P.vz = tb->pair[3]; P.vzn = tb->pair[4]; P.gy = tb->pair[5];
+        P.xref = tb->r_xref;
+        P.xref_inst_stride = (tb->in_xref.set && !tb->in_xref.shared) ? (long long)tb->N * 16 : 0;
+        P.xref_table = tb->tab_row; P.xref_start = tb->xref_start; P.table_rows = tb->table_rows;
+        P.bounds = tb->r_bounds;
+        P.mats = (v == VAR_ROW_EXACT) ? tb->mats_exact : tb->mats_fast;
+        P.res = tb->res; P.status = tb->status; P.iter = tb->iter; P.n_unsolved = tb->n_unsolved;
+        e = launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, P, tb->stream);
+    }
     if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
     if (tb->timing)
     {
@@ -402,18 +663,21 @@ int launch_solve(TinyBatch *tb)
     return 0;
 }
 
-int set_bound(TinyBatch *tb, const float *src, int shared, float **slot, bool xfam, bool *shared_flags, int which)
+int set_bound(TinyBatch *tb, const float *src, int shared, int which)
 {
     CHECK_TB(tb);
     CHECK_PTR(src);
-    if (set_device(tb)) return TINY_BATCH_EHIP;
-    // Both arrays of a pair (min,max) must end up in the same sharing mode (checked at solve time):
-    // the kernel walks them with one tile stride.
-    const int steps = xfam ? tb->N : tb->N - 1;
-    int rc = upload_packed(tb, src, *slot, xfam, shared != 0, 0, steps);
-    if (rc) return rc;
-    shared_flags[which] = shared != 0;
-    return 0;
+    TRY(set_device(tb));
+    const bool xf = which < 2;
+    return store_input(tb, tb->in_bnd[which], src, shared != 0, xf ? tb->N : tb->N - 1, xf ? tb->nx : tb->nu);
+}
+
+bool stream_dims_supported(int nxc, int nuc)
+{
+#define TINY_CHECK_DIMS(NXC, NUC) \
+    if (nxc == NXC && nuc == NUC) return true;
+    TINY_FOR_EACH_DIMS(TINY_CHECK_DIMS)
+    return false;
 }
 
 } // namespace
@@ -430,42 +694,35 @@ int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int dev
     if (nx < 1 || nu < 1 || N < 2 || batch < 1)
         return fail(TINY_BATCH_EINVAL, "tiny_batch_create: need nx>=1, nu>=1, N>=2, batch>=1 (got %d,%d,%d,%d)", nx, nu, N, batch);
     const int nxc = (nx + 3) / 4, nuc = (nu + 3) / 4;
-    if (!dims_supported(nxc, nuc))
+    const bool tile_ok = stream_dims_supported(nxc, nuc), row_ok = rowlane_supported(nx, nu, N);
+    if (!tile_ok && !row_ok)
         return fail(TINY_BATCH_EUNSUPPORTED,
-                    "no kernel instantiation for nx=%d nu=%d (chunks %d,%d); add it to TINY_FOR_EACH_DIMS", nx, nu, nxc, nuc);
+                    "no kernel instantiation for nx=%d nu=%d N=%d; add it to TINY_FOR_EACH_DIMS / TINY_FOR_EACH_ROWLANE", nx, nu, N);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(TINY_BATCH_EINVAL, "device %d out of range (have %d)", device, ndev);
     TinyBatch *tb = new TinyBatch();
     tb->nx = nx; tb->nu = nu; tb->N = N; tb->batch = batch; tb->device = device;
-    tb->NXC = nxc; tb->NUC = nuc; tb->ntiles = (batch + TILE - 1) / TILE;
+    tb->NXC = nxc; tb->NUC = nuc; tb->ntiles = (batch + TILE - 1) / TILE; tb->bpad4 = (batch + 3) / 4 * 4;
+    tb->tile_dims_ok = tile_ok; tb->row_dims_ok = row_ok;
     tb->xfam_floats = (size_t)tb->ntiles * N * WAVE * nxc;
     tb->ufam_floats = (size_t)tb->ntiles * (N - 1) * WAVE * nuc;
+    tb->pair_floats = (size_t)tb->bpad4 * N * 16;
+    tb->layout = row_ok ? LAYOUT_ROW : LAYOUT_TILE;
     auto cleanup = [&](int rc) { tiny_batch_destroy(tb); return rc; };
     if (hipSetDevice(device) != hipSuccess) return cleanup(fail(TINY_BATCH_EHIP, "hipSetDevice(%d) failed", device));
-#define ALLOC(ptr, nfloats)                                                                           \
-    do                                                                                                \
-    {                                                                                                 \
-        hipError_t e_ = hipMalloc((void **)&(ptr), (size_t)(nfloats) * sizeof(float));                \
-        if (e_ == hipSuccess) e_ = hipMemset((ptr), 0, (size_t)(nfloats) * sizeof(float));            \
-        if (e_ != hipSuccess) return cleanup(fail(TINY_BATCH_EHIP, "hipMalloc/hipMemset(%zu B) failed: %s", \
-                                                  (size_t)(nfloats) * sizeof(float), hipGetErrorString(e_))); \
-    } while (0)
-    for (int id = 0; id < TINY_ARR_COUNT; id++) ALLOC(tb->arr[id], is_xfam(id) ? tb->xfam_floats : tb->ufam_floats);
-    ALLOC(tb->xmin, tb->xfam_floats); ALLOC(tb->xmax, tb->xfam_floats); ALLOC(tb->xref, tb->xfam_floats);
-    ALLOC(tb->umin, tb->ufam_floats); ALLOC(tb->umax, tb->ufam_floats);
-    ALLOC(tb->res, (size_t)batch * 4);
-    ALLOC(tb->status, batch); ALLOC(tb->iter, batch); ALLOC(tb->n_unsolved, 1);
-    ALLOC(tb->xref_start, batch);
-    ALLOC(tb->x0buf, (size_t)batch * nx);
+    if (int rc = alloc_layout(tb, tb->layout)) return cleanup(rc);
+    if (int rc = dev_alloc_zero(&tb->res, (size_t)batch * 4)) return cleanup(rc);
+    if (int rc = dev_alloc_zero((float **)&tb->status, batch)) return cleanup(rc);
+    if (int rc = dev_alloc_zero((float **)&tb->iter, batch)) return cleanup(rc);
+    if (int rc = dev_alloc_zero((float **)&tb->n_unsolved, 1)) return cleanup(rc);
+    if (int rc = dev_alloc_zero((float **)&tb->xref_start, batch)) return cleanup(rc);
+    if (int rc = dev_alloc_zero(&tb->x0buf, (size_t)batch * nx)) return cleanup(rc);
     tb->staging_floats = (size_t)batch * N * (nx > nu ? nx : nu);
-    ALLOC(tb->staging, tb->staging_floats);
-#undef ALLOC
+    if (int rc = dev_alloc_zero(&tb->staging, tb->staging_floats)) return cleanup(rc);
     if (hipEventCreate(&tb->ev0) != hipSuccess || hipEventCreate(&tb->ev1) != hipSuccess)
         return cleanup(fail(TINY_BATCH_EHIP, "hipEventCreate failed"));
-    char nm[64];
-    snprintf(nm, sizeof nm, "stream<%d,%d>", nxc, nuc);
-    tb->kname = nm;
+    update_kname(tb);
     *out = tb;
     return TINY_BATCH_OK;
 }
@@ -474,12 +731,15 @@ void tiny_batch_destroy(TinyBatch *tb)
 {
     if (!tb) return;
     (void)hipSetDevice(tb->device);
-    for (int id = 0; id < TINY_ARR_COUNT; id++) (void)hipFree(tb->arr[id]);
-    (void)hipFree(tb->xmin); (void)hipFree(tb->xmax); (void)hipFree(tb->umin); (void)hipFree(tb->umax);
-    (void)hipFree(tb->xref); (void)hipFree(tb->xref_table); (void)hipFree(tb->xref_start);
+    free_layout(tb, LAYOUT_TILE);
+    free_layout(tb, LAYOUT_ROW);
+    (void)hipFree(tb->in_xref.dev);
+    for (int k = 0; k < 4; k++) { (void)hipFree(tb->in_bnd[k].dev); (void)hipFree(tb->t_bnd[k]); }
+    (void)hipFree(tb->t_xref); (void)hipFree(tb->r_xref); (void)hipFree(tb->r_bounds);
+    (void)hipFree(tb->tab_tile); (void)hipFree(tb->tab_row); (void)hipFree(tb->xref_start);
     (void)hipFree(tb->res); (void)hipFree(tb->status); (void)hipFree(tb->iter); (void)hipFree(tb->n_unsolved);
-    (void)hipFree(tb->opnd); (void)hipFree(tb->qvec); (void)hipFree(tb->dA); (void)hipFree(tb->dB);
-    (void)hipFree(tb->x0buf); (void)hipFree(tb->staging);
+    (void)hipFree(tb->opnd); (void)hipFree(tb->qvec); (void)hipFree(tb->mats_exact); (void)hipFree(tb->mats_fast);
+    (void)hipFree(tb->dA); (void)hipFree(tb->dB); (void)hipFree(tb->x0buf); (void)hipFree(tb->staging);
     if (tb->ev0) (void)hipEventDestroy(tb->ev0);
     if (tb->ev1) (void)hipEventDestroy(tb->ev1);
     delete tb;
@@ -495,7 +755,7 @@ int tiny_batch_set_stream(TinyBatch *tb, void *hip_stream)
 int tiny_batch_synchronize(TinyBatch *tb)
 {
     CHECK_TB(tb);
-    if (set_device(tb)) return TINY_BATCH_EHIP;
+    TRY(set_device(tb));
     HIP_TRY(hipStreamSynchronize(tb->stream));
     return 0;
 }
@@ -511,7 +771,7 @@ int tiny_batch_set_cache(TinyBatch *tb, float rho, const float *Kinf, const floa
     tb->Quu_inv.assign(Quu_inv, Quu_inv + (size_t)nu * nu);
     tb->AmBKt.assign(AmBKt, AmBKt + (size_t)nx * nx);
     tb->have_cache = true;
-    tb->operands_dirty = true;
+    tb->gains_dirty = true;
     return 0;
 }
 
@@ -523,7 +783,7 @@ int tiny_batch_set_dynamics(TinyBatch *tb, const float *Adyn, const float *Bdyn,
     tb->Bdyn.assign(Bdyn, Bdyn + (size_t)nx * nu);
     tb->Q.assign(Q, Q + nx);
     tb->have_dyn = true;
-    tb->operands_dirty = true;
+    tb->gains_dirty = true;
     return 0;
 }
 
@@ -533,6 +793,7 @@ int tiny_batch_set_settings(TinyBatch *tb, float abs_pri_tol, float abs_dua_tol,
     CHECK_TB(tb);
     if (check_termination < 1)
         return fail(TINY_BATCH_EINVAL, "check_termination must be >= 1 (the reference computes iter %% check_termination, admm.cpp:93)");
+    if (tb->en_state_bound != en_state_bound || tb->en_input_bound != en_input_bound) tb->derived_dirty[LAYOUT_ROW] = true;
     tb->abs_pri_tol = abs_pri_tol; tb->abs_dua_tol = abs_dua_tol;
     tb->max_iter = max_iter; tb->check_termination = check_termination;
     tb->en_state_bound = en_state_bound; tb->en_input_bound = en_input_bound;
@@ -543,30 +804,24 @@ int tiny_batch_set_settings(TinyBatch *tb, float abs_pri_tol, float abs_dua_tol,
 int tiny_batch_set_x0(TinyBatch *tb, const float *x0)
 {
     CHECK_TB(tb); CHECK_PTR(x0);
-    if (set_device(tb)) return TINY_BATCH_EHIP;
+    TRY(set_device(tb));
     HIP_TRY(hipMemcpyAsync(tb->x0buf, x0, (size_t)tb->batch * tb->nx * sizeof(float), hipMemcpyHostToDevice, tb->stream));
-    return upload_packed(tb, x0, tb->arr[TINY_ARR_X], true, false, 0, 1);
+    return upload_work(tb, x0, TINY_ARR_X, 0, 1);
 }
 
 int tiny_batch_set_x0_device(TinyBatch *tb, const float *d_x0)
 {
     CHECK_TB(tb); CHECK_PTR(d_x0);
-    if (set_device(tb)) return TINY_BATCH_EHIP;
+    TRY(set_device(tb));
     HIP_TRY(hipMemcpyAsync(tb->x0buf, d_x0, (size_t)tb->batch * tb->nx * sizeof(float), hipMemcpyDeviceToDevice, tb->stream));
-    const long long total = (long long)tb->ntiles * WAVE * tb->NXC;
-    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(256), 0, tb->stream, d_x0, tb->arr[TINY_ARR_X],
-                       tb->batch, 0, tb->nx, tb->NXC, tb->ntiles, tb->N, 0, 1);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return launch_pack(tb, d_x0, work_ptr(tb, TINY_ARR_X), tb->layout, 0, tb->batch, false, 0, 1);
 }
 
 int tiny_batch_set_xref(TinyBatch *tb, const float *xref, int shared)
 {
     CHECK_TB(tb); CHECK_PTR(xref);
-    if (set_device(tb)) return TINY_BATCH_EHIP;
-    int rc = upload_packed(tb, xref, tb->xref, true, shared != 0, 0, tb->N);
-    if (rc) return rc;
-    tb->xref_shared = shared != 0;
+    TRY(set_device(tb));
+    TRY(store_input(tb, tb->in_xref, xref, shared != 0, tb->N, tb->nx));
     tb->xref_mode = 0;
     return 0;
 }
@@ -578,19 +833,23 @@ int tiny_batch_set_xref_window(TinyBatch *tb, const float *table, int rows, cons
     for (int b = 0; b < tb->batch; b++)
         if (start[b] < 0 || start[b] + tb->N > rows)
             return fail(TINY_BATCH_EINVAL, "window start[%d]=%d out of range for %d rows, N=%d", b, start[b], rows, tb->N);
-    if (set_device(tb)) return TINY_BATCH_EHIP;
-    // table layout on device: [rows][4 gq][NXC]
-    std::vector<float> t((size_t)rows * 4 * tb->NXC, 0.f);
+    TRY(set_device(tb));
+    // table on the device in both forms: [rows][4 gq][NXC] (streaming kernel) and [rows][16] (rowlane kernel)
+    std::vector<float> tt((size_t)rows * 4 * tb->NXC, 0.f), tr((size_t)rows * 16, 0.f);
     for (int r = 0; r < rows; r++)
-        for (int gq = 0; gq < 4; gq++)
-            for (int ch = 0; ch < tb->NXC; ch++)
-            {
-                int row = 4 * ch + gq;
-                if (row < tb->nx) t[((size_t)r * 4 + gq) * tb->NXC + ch] = table[(size_t)r * tb->nx + row];
-            }
-    if (tb->xref_table && tb->table_rows != rows) { (void)hipFree(tb->xref_table); tb->xref_table = nullptr; }
-    if (!tb->xref_table) HIP_TRY(hipMalloc((void **)&tb->xref_table, t.size() * sizeof(float)));
-    HIP_TRY(hipMemcpyAsync(tb->xref_table, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, tb->stream));
+        for (int row = 0; row < tb->nx; row++)
+        {
+            const float v = table[(size_t)r * tb->nx + row];
+            tt[((size_t)r * 4 + (row & 3)) * tb->NXC + (row >> 2)] = v;
+            if (row < 16) tr[(size_t)r * 16 + row] = v;
+        }
+    if (tb->table_rows != rows)
+    {
+        (void)hipFree(tb->tab_tile); (void)hipFree(tb->tab_row);
+        tb->tab_tile = tb->tab_row = nullptr;
+    }
+    TRY(upload_vec(tb, &tb->tab_tile, tt));
+    TRY(upload_vec(tb, &tb->tab_row, tr));
     HIP_TRY(hipMemcpyAsync(tb->xref_start, start, (size_t)tb->batch * sizeof(int), hipMemcpyHostToDevice, tb->stream));
     HIP_TRY(hipStreamSynchronize(tb->stream));
     tb->table_rows = rows;
@@ -598,10 +857,10 @@ int tiny_batch_set_xref_window(TinyBatch *tb, const float *table, int rows, cons
     return 0;
 }
 
-int tiny_batch_set_umin(TinyBatch *tb, const float *s, int shared) { CHECK_TB(tb); return set_bound(tb, s, shared, &tb->umin, false, tb->ub_shared, 0); }
-int tiny_batch_set_umax(TinyBatch *tb, const float *s, int shared) { CHECK_TB(tb); return set_bound(tb, s, shared, &tb->umax, false, tb->ub_shared, 1); }
-int tiny_batch_set_xmin(TinyBatch *tb, const float *s, int shared) { CHECK_TB(tb); return set_bound(tb, s, shared, &tb->xmin, true, tb->xb_shared, 0); }
-int tiny_batch_set_xmax(TinyBatch *tb, const float *s, int shared) { CHECK_TB(tb); return set_bound(tb, s, shared, &tb->xmax, true, tb->xb_shared, 1); }
+int tiny_batch_set_xmin(TinyBatch *tb, const float *s, int shared) { return set_bound(tb, s, shared, 0); }
+int tiny_batch_set_xmax(TinyBatch *tb, const float *s, int shared) { return set_bound(tb, s, shared, 1); }
+int tiny_batch_set_umin(TinyBatch *tb, const float *s, int shared) { return set_bound(tb, s, shared, 2); }
+int tiny_batch_set_umax(TinyBatch *tb, const float *s, int shared) { return set_bound(tb, s, shared, 3); }
 
 int tiny_batch_reset_dual_variables(TinyBatch *tb)
 {
@@ -613,15 +872,13 @@ int tiny_batch_reset_dual_variables(TinyBatch *tb)
 int tiny_batch_solve_async(TinyBatch *tb)
 {
     CHECK_TB(tb);
-    if (tb->xb_shared[0] != tb->xb_shared[1] || tb->ub_shared[0] != tb->ub_shared[1])
-        return fail(TINY_BATCH_EINVAL, "min and max bounds must both be shared or both be per-instance");
     return launch_solve(tb);
 }
 
 int tiny_batch_wait(TinyBatch *tb, int *n_unsolved)
 {
     CHECK_TB(tb);
-    if (set_device(tb)) return TINY_BATCH_EHIP;
+    TRY(set_device(tb));
     int n = 0;
     HIP_TRY(hipMemcpyAsync(&n, tb->n_unsolved, sizeof(int), hipMemcpyDeviceToHost, tb->stream));
     HIP_TRY(hipStreamSynchronize(tb->stream));
@@ -631,11 +888,9 @@ int tiny_batch_wait(TinyBatch *tb, int *n_unsolved)
 
 int tiny_batch_solve(TinyBatch *tb)
 {
-    int rc = tiny_batch_solve_async(tb);
-    if (rc) return rc;
+    TRY(tiny_batch_solve_async(tb));
     int n = 0;
-    rc = tiny_batch_wait(tb, &n);
-    if (rc) return rc;
+    TRY(tiny_batch_wait(tb, &n));
     return n > 0 ? 1 : 0;
 }
 
@@ -645,7 +900,7 @@ int tiny_batch_get_u(TinyBatch *tb, float *u) { return tiny_batch_get_array(tb, 
 int tiny_batch_get_status(TinyBatch *tb, int *iter, int *status, float *residuals)
 {
     CHECK_TB(tb);
-    if (set_device(tb)) return TINY_BATCH_EHIP;
+    TRY(set_device(tb));
     if (iter) HIP_TRY(hipMemcpyAsync(iter, tb->iter, (size_t)tb->batch * sizeof(int), hipMemcpyDeviceToHost, tb->stream));
     if (status) HIP_TRY(hipMemcpyAsync(status, tb->status, (size_t)tb->batch * sizeof(int), hipMemcpyDeviceToHost, tb->stream));
     if (residuals) HIP_TRY(hipMemcpyAsync(residuals, tb->res, (size_t)tb->batch * 4 * sizeof(float), hipMemcpyDeviceToHost, tb->stream));
@@ -656,7 +911,7 @@ int tiny_batch_get_status(TinyBatch *tb, int *iter, int *status, float *residual
 int tiny_batch_set_status(TinyBatch *tb, const int *iter, const int *status, const float *residuals)
 {
     CHECK_TB(tb);
-    if (set_device(tb)) return TINY_BATCH_EHIP;
+    TRY(set_device(tb));
     if (iter) HIP_TRY(hipMemcpyAsync(tb->iter, iter, (size_t)tb->batch * sizeof(int), hipMemcpyHostToDevice, tb->stream));
     if (status) HIP_TRY(hipMemcpyAsync(tb->status, status, (size_t)tb->batch * sizeof(int), hipMemcpyHostToDevice, tb->stream));
     if (residuals) HIP_TRY(hipMemcpyAsync(tb->res, residuals, (size_t)tb->batch * 4 * sizeof(float), hipMemcpyHostToDevice, tb->stream));
@@ -668,17 +923,11 @@ int tiny_batch_set_array(TinyBatch *tb, int id, const float *src)
 {
     CHECK_TB(tb); CHECK_PTR(src);
     if (id < 0 || id >= TINY_ARR_COUNT) return fail(TINY_BATCH_EINVAL, "bad array id %d", id);
-    if (set_device(tb)) return TINY_BATCH_EHIP;
-    if (int rc = flush_pending(tb)) return rc;
-    const bool xf = is_xfam(id);
-    int rc = upload_packed(tb, src, tb->arr[id], xf, false, 0, xf ? tb->N : tb->N - 1);
-    if (rc) return rc;
+    TRY(set_device(tb));
+    TRY(flush_pending(tb));
+    TRY(upload_work(tb, src, id, 0, is_xfam(id) ? tb->N : tb->N - 1));
     if (id == TINY_ARR_X) // keep the closed-loop state buffer coherent with x.col(0)
-    {
-        hipLaunchKernelGGL(unpack_kernel, dim3(grid_for((long long)tb->batch * tb->nx)), dim3(256), 0, tb->stream,
-                           tb->arr[TINY_ARR_X], tb->x0buf, tb->batch, tb->nx, tb->NXC, tb->N, 0, 1);
-        HIP_TRY(hipGetLastError());
-    }
+        TRY(launch_unpack(tb, work_ptr(tb, TINY_ARR_X), tb->x0buf, tb->layout, 0, tb->batch, 0, 1));
     return 0;
 }
 
@@ -686,22 +935,19 @@ int tiny_batch_get_array(TinyBatch *tb, int id, float *dst)
 {
     CHECK_TB(tb); CHECK_PTR(dst);
     if (id < 0 || id >= TINY_ARR_COUNT) return fail(TINY_BATCH_EINVAL, "bad array id %d", id);
-    if (set_device(tb)) return TINY_BATCH_EHIP;
-    if (int rc = flush_pending(tb)) return rc;
-    const bool xf = is_xfam(id);
-    return download_unpacked(tb, tb->arr[id], dst, xf, 0, xf ? tb->N : tb->N - 1);
+    TRY(set_device(tb));
+    TRY(flush_pending(tb));
+    return download_work(tb, id, dst, 0, is_xfam(id) ? tb->N : tb->N - 1);
 }
 
 int tiny_batch_reset_workspace(TinyBatch *tb)
 {
     CHECK_TB(tb);
-    if (set_device(tb)) return TINY_BATCH_EHIP;
-    // x.col(0) (the x0 the caller sets next) is zeroed now; everything else is zeroed lazily: the next solve reads d,v,z,y,g as zero in its first iteration and overwrites the rest, any other
-    // reader triggers the memsets (flush_pending).
-    {
-        const size_t step_bytes = (size_t)WAVE * tb->NXC * sizeof(float);
-        HIP_TRY(hipMemset2DAsync(tb->arr[TINY_ARR_X], step_bytes * tb->N, 0, step_bytes, tb->ntiles, tb->stream)); // x.col(0)
-    }
+    TRY(set_device(tb));
+    // x.col(0) (the x0 the caller sets next) is zeroed now; everything else is zeroed lazily: the next solve
+    // reads d,v,z,y,g (and p) as zero in its first iteration and overwrites the rest, any other reader triggers the
+    // zero fill (flush_pending).
+    TRY(launch_zero(tb, work_ptr(tb, TINY_ARR_X), tb->layout, 0, 0, 1));
     HIP_TRY(hipMemsetAsync(tb->res, 0, (size_t)tb->batch * 4 * sizeof(float), tb->stream));
     HIP_TRY(hipMemsetAsync(tb->status, 0, (size_t)tb->batch * sizeof(int), tb->stream));
     HIP_TRY(hipMemsetAsync(tb->iter, 0, (size_t)tb->batch * sizeof(int), tb->stream));
@@ -714,12 +960,8 @@ int tiny_batch_reset_workspace(TinyBatch *tb)
 int tiny_batch_get_u0_device(TinyBatch *tb, float *d_u0)
 {
     CHECK_TB(tb); CHECK_PTR(d_u0);
-    if (set_device(tb)) return TINY_BATCH_EHIP;
-    const int n = tb->batch * tb->nu;
-    hipLaunchKernelGGL(gather_u0_kernel, dim3((n + 255) / 256), dim3(256), 0, tb->stream, tb->arr[TINY_ARR_U], d_u0,
-                       tb->batch, tb->nu, tb->NUC, tb->N);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    TRY(set_device(tb));
+    return launch_unpack(tb, work_ptr(tb, TINY_ARR_U), d_u0, tb->layout, 1, tb->batch, 0, 1);
 }
 
 int tiny_batch_mpc_step_async(TinyBatch *tb, int window_advance)
@@ -728,12 +970,10 @@ int tiny_batch_mpc_step_async(TinyBatch *tb, int window_advance)
     if (tb->nx > 64) return fail(TINY_BATCH_EUNSUPPORTED, "mpc_step supports nx <= 64");
     // x.col(0) already holds x0 (set_x0 / previous plant step); reset duals, solve, then simulate forward.
     tb->duals_zero_pending = true;
-    int rc = tiny_batch_solve_async(tb);
-    if (rc) return rc;
+    TRY(tiny_batch_solve_async(tb));
     hipLaunchKernelGGL(plant_step_kernel, dim3((tb->batch + 127) / 128), dim3(128), 0, tb->stream, tb->x0buf,
-                       tb->arr[TINY_ARR_X], tb->arr[TINY_ARR_U], tb->dA, tb->dB,
-                       tb->xref_mode == 1 ? tb->xref_start : nullptr, window_advance, tb->batch, tb->nx, tb->nu, tb->NXC,
-                       tb->NUC, tb->N);
+                       work_ptr(tb, TINY_ARR_X), work_ptr(tb, TINY_ARR_U), tb->dA, tb->dB,
+                       tb->xref_mode == 1 ? tb->xref_start : nullptr, window_advance, tb->batch, tb->layout, geo(tb));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -741,7 +981,7 @@ int tiny_batch_mpc_step_async(TinyBatch *tb, int window_advance)
 int tiny_batch_get_x0(TinyBatch *tb, float *x0)
 {
     CHECK_TB(tb); CHECK_PTR(x0);
-    if (set_device(tb)) return TINY_BATCH_EHIP;
+    TRY(set_device(tb));
     HIP_TRY(hipMemcpyAsync(x0, tb->x0buf, (size_t)tb->batch * tb->nx * sizeof(float), hipMemcpyDeviceToHost, tb->stream));
     HIP_TRY(hipStreamSynchronize(tb->stream));
     return 0;
@@ -759,20 +999,30 @@ int tiny_batch_last_solve_ms(TinyBatch *tb, float *ms)
 {
     CHECK_TB(tb); CHECK_PTR(ms);
     if (!tb->ev_valid) return fail(TINY_BATCH_ENOTREADY, "no timed solve recorded (call tiny_batch_enable_timing first)");
-    if (set_device(tb)) return TINY_BATCH_EHIP;
+    TRY(set_device(tb));
     HIP_TRY(hipEventSynchronize(tb->ev1));
     HIP_TRY(hipEventElapsedTime(ms, tb->ev0, tb->ev1));
     return 0;
 }
 
-const char *tiny_batch_kernel_name(TinyBatch *tb) { return tb ? tb->kname.c_str() : ""; }
+const char *tiny_batch_kernel_name(TinyBatch *tb)
+{
+    if (!tb) return "";
+    update_kname(tb);
+    return tb->kname.c_str();
+}
 
 int tiny_batch_select_kernel(TinyBatch *tb, int variant)
 {
     CHECK_TB(tb);
-    if (variant < 0 || variant > 2) return fail(TINY_BATCH_EINVAL, "variant must be 0 (auto), 1 (stream) or 2 (resident)");
-    if (variant == 2) return fail(TINY_BATCH_EUNSUPPORTED, "resident kernel not available for nx=%d nu=%d N=%d", tb->nx, tb->nu, tb->N);
+    if (variant < VAR_AUTO || variant > VAR_ROW_FAST)
+        return fail(TINY_BATCH_EINVAL, "variant must be 0 (auto), 1 (streaming), 2 (rowlane exact) or 3 (rowlane fast)");
+    const int old = tb->variant;
     tb->variant = variant;
+    int v = 0;
+    if (int rc = resolve_variant(tb, &v)) { tb->variant = old; return rc; }
+    TRY(set_device(tb));
+    TRY(ensure_layout(tb, v == VAR_STREAM ? LAYOUT_TILE : LAYOUT_ROW));
     return 0;
 }
 

@@ -71,7 +71,36 @@ struct SolveParams
     const float *qvec; // [64][NXC]  Q(row) per lane
 };
 
+// (nx, nu, N) triples with a compiled register-resident kernel (admm_rowlane.hip); needs nx + nu <= 16
+#define TINY_FOR_EACH_ROWLANE(X) X(12, 4, 30) X(12, 4, 10) X(4, 1, 10) X(8, 3, 7)
+
+// "Row" layout used by the rowlane kernel: the twelve work arrays are stored as six stacked pairs
+//   xu = [x;u], qr = [q;r], pd = [p;d], vz = [v;z], vzn = [vnew;znew], gy = [g;y]
+// each float [batch_pad4][N][16]: row r < nx is the state-type member, nx <= r < nx+nu the input-type
+// member (zero at step N-1), the rest zero.  One DPP row (16 lanes) = one instance-step = 64 contiguous bytes.
+struct RowParams
+{
+    int nx, nu, N, batch;
+    float rho, abs_pri_tol, abs_dua_tol;
+    int max_iter, check_termination;
+    int duals_zero, cold_start;
+    int xref_mode;               // 0: xref array (stride 0 = shared), 1: window gather
+    float *xu, *qr, *pd, *vz, *vzn, *gy;
+    const float *xref;           // [batch or 1][N][16]
+    long long xref_inst_stride;  // floats between instances (0 = shared)
+    const float *xref_table;     // [rows][16]
+    const int *xref_start;
+    int table_rows;
+    const float *bounds;         // [N][16][2] = {lo, hi}; +-inf where a bound is disabled or the row is unused
+    const float *mats;           // [3nx + 2nu + 1][16] gain rows per lane (see pack_row_mats)
+    float *res;
+    int *status, *iter, *n_unsolved;
+};
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+bool rowlane_supported(int nx, int nu, int N);
+hipError_t launch_admm_rowlane(int nx, int nu, int N, bool exact, const RowParams &P, hipStream_t stream);
 
 hipError_t launch_admm_stream(int nxc, int nuc, const SolveParams &P, hipStream_t stream);
 
