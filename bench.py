@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--mode", choices=["early_exit", "fixed10"], default="early_exit")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 streaming, 2 resident")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto (rowlane exact), 1 streaming, 2 rowlane exact, 3 rowlane fast")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -121,9 +121,10 @@ def main():
     pr = T.problems
     prob = pr.quadrotor(20, N)
     B = args.batch
-    # shard = contiguous block of the global instance index; each rank draws its own block
+    # shard = contiguous block of the global instance index; weak scaling: B instances per rank
     gx0, table, gstart = pr.tracking_batch(B * world, N)
-    x0, start = gx0[rank * B:(rank + 1) * B], gstart[rank * B:(rank + 1) * B]
+    lo, hi = T.sharding.block_partition(B * world, world, rank)
+    x0, start = gx0[lo:hi], gstart[lo:hi]
     settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1, en_state_bound=1, en_input_bound=1)
     if args.mode == "fixed10":
         settings.update(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=10)
@@ -164,18 +165,25 @@ def main():
         kernel_ms.append(sol.last_solve_ms())
     n_unsolved = sol.wait()
     iters, status, _ = sol.get_status()
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    stats = torch.tensor([float(iters.sum()), float((status == 1).sum()), flops_of(iters, status), float(iters.max())],
-                         dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        mx = stats[3:].clone()
-        dist.all_reduce(stats[:3], op=dist.ReduceOp.SUM)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        stats[3:] = mx
-    dt = float(t.item())
+    agg = T.sharding.reduce_stats(dist, "cuda", iters, status, flops_of(iters, status), dt)
+    dt = agg["wall_s"]  # max over ranks
     total_solves = B * world * args.steps
     value = total_solves / dt
+    # the opt-in fma-chain arithmetic of the same kernel, for reference (not the headline: see DESIGN.md §3)
+    fast = None
+    if rank == 0 and not args.kernel and sol.kernel_name().startswith("rowlane"):
+        sol.select_kernel(3)
+        for _ in range(2):
+            step()
+        ms = []
+        for _ in range(min(args.steps, 10)):
+            step()
+            ms.append(sol.last_solve_ms())
+        itf, stf, _ = sol.get_status()
+        fast = dict(kernel=sol.kernel_name(), kernel_ms=float(np.mean(ms)), solves_per_s=B / (float(np.mean(ms)) * 1e-3),
+                    f32_frac=flops_of(itf, stf) / (float(np.mean(ms)) * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                    mean_iters=float(itf.mean()), note="kernel time only; parity bar = the reference's own fp64/fp32 spread")
+        sol.select_kernel(0)
 
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
@@ -209,10 +217,12 @@ def main():
                                    f"{args.mode} (tol 1e-3, max_iter 100)" if args.mode == "early_exit" else
                                    f"quadrotor_tracking batched {B} instances per GPU, cold-start tiny_solve, fixed 10 iterations",
                        "nx": NX, "nu": NU, "N": N, "instances_per_gpu": B, "parallelism": f"batch-shard x{world}",
-                       "kernel": sol.kernel_name(), "mean_iters": float(stats[0].item()) / (B * world),
-                       "max_iters": int(stats[3].item()), "frac_converged": float(stats[1].item()) / (B * world)},
+                       "kernel": sol.kernel_name(), "mean_iters": agg["sum_iters"] / agg["n_instances"],
+                       "max_iters": agg["max_iters"], "frac_converged": agg["n_converged"] / agg["n_instances"]},
             "roofline": roof,
         }
+        if fast is not None:
+            line["fast_arithmetic"] = fast
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(prob, pr)
         print(json.dumps(line), flush=True)

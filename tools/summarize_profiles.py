@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into the committed summaries under profiles/:
+   <tag>_<kernel>_kernel_stats.csv, <tag>_<kernel>_pmc.json and the hbm_traffic.json that bench.py reads."""
+import csv, glob, json, sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = ROOT / "gpurun_out" / f"prof_{tag}"
+prof = ROOT / "profiles"
+
+
+def counter_rows(d):
+    rows = []
+    for f in glob.glob(str(src / d / "**" / "*counter_collection.csv"), recursive=True):
+        rows += list(csv.DictReader(open(f)))
+    return rows
+
+
+def per_kernel(rows, counter):
+    acc = {}
+    for r in rows:
+        if r.get("Counter_Name") != counter:
+            continue
+        acc.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    return acc
+
+
+out = {}
+CALIB_BYTES = float(1 << 30)
+factors = {}
+for c, kname in (("FETCH_SIZE", "calib_read"), ("WRITE_SIZE", "calib_write")):
+    cal = per_kernel(counter_rows(f"calib_{c}"), c)
+    vals = [v for k, vs in cal.items() if kname in k for v in vs]
+    factors[c] = CALIB_BYTES / (sum(vals) / len(vals)) if vals else None
+out["calibration"] = {"bytes_per_launch": CALIB_BYTES, "bytes_per_count": factors,
+                      "note": "bytes per counter unit measured on tools/micro/hbm_calib (dword per lane, 256 B per wave-instruction)"}
+kern = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for k, vs in per_kernel(counter_rows(f"pmc_{c}"), c).items():
+        if "admm_" in k:
+            kern.setdefault(k, {})[c] = sum(vs) / len(vs)
+for k, d in kern.items():
+    rd = d.get("FETCH_SIZE", 0) * (factors["FETCH_SIZE"] or 0)
+    wr = d.get("WRITE_SIZE", 0) * (factors["WRITE_SIZE"] or 0)
+    d.update(read_bytes=rd, write_bytes=wr, hbm_bytes=rd + wr)
+out["kernels"] = kern
+sq = {}
+for r in counter_rows("pmc_sq"):
+    if "admm_" in r["Kernel_Name"]:
+        sq.setdefault(r["Kernel_Name"], {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+out["sq"] = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in sq.items()}
+line = None
+for l in open(src / "bench_stats.log"):
+    if l.startswith("{"):
+        line = json.loads(l)
+out["bench_line_under_profiler"] = line
+kshort = (line["roofline"]["kernel"] if line else "kernel").replace("<", "_").replace(">", "").replace(",", "_")
+(prof / f"{tag}_{kshort}_pmc.json").write_text(json.dumps(out, indent=1))
+for f in glob.glob(str(src / "stats" / "**" / "*kernel_stats.csv"), recursive=True):
+    (prof / f"{tag}_{kshort}_kernel_stats.csv").write_text(open(f).read())
+# the table bench.py reads: "<kernel name>:<mode>:<batch>" -> HBM bytes per launch
+tf = prof / "hbm_traffic.json"
+table = json.loads(tf.read_text()) if tf.exists() else {}
+if line:
+    for k, d in kern.items():
+        table[f"{line['roofline']['kernel']}:early_exit:{line['config']['instances_per_gpu']}"] = d["hbm_bytes"]
+tf.write_text(json.dumps(table, indent=1))
+print(json.dumps({k: v for k, v in out.items() if k != "bench_line_under_profiler"}, indent=1)[:3000])
