@@ -134,14 +134,14 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
 
     // ---- box bounds of the whole horizon, shared by the batch: LDS table [N][16] of {lo, hi} ----
     __shared__ float2 bnd[N * 16];
-    // vnew/znew of the current sweep and the p history live in LDS (lane-linear => conflict free): they are
-    // written once and read once per iteration (sn) or only at the end (ps), so they do not need a VGPR each.
+    // vnew/znew of the current sweep (sn) and the previous slack v/z (b) live in LDS (lane-linear => conflict free):
+    // each is written once and read once per iteration, so they do not need a VGPR per horizon step.
     __shared__ float sn_lds[N * WAVE];
-    __shared__ float ps_lds[(N - 1) * WAVE];
+    __shared__ float b_lds[N * WAVE];
     for (int e = lane; e < N * 16; e += WAVE) bnd[e] = reinterpret_cast<const float2 *>(P.bounds)[e];
     __syncthreads();
     float *sn = sn_lds + lane;   // sn[i * WAVE]
-    float *ps = ps_lds + lane;   // ps[i * WAVE]
+    float *b = b_lds + lane;     // b[i * WAVE]
 
     // ---- gain rows of this lane -----------------------------------------------------------------
     float M1[NX], M2[NU], M3[NX], M45[NU];
@@ -158,16 +158,19 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
     }
 
     // ---- per-instance state, all in registers --------------------------------------------------------
-    //   a[i]  : g_i (x rows) | y_i (u rows)           duals
-    //   b[i]  : v_i          | z_i                    previous slack
-    //   c[i]  : -(Xref_i.*Q) | d_i                    reference cost term | Riccati feed-forward
-    //   sn[i] : vnew_i       | znew_i                 current slack                     (LDS)
-    //   ps[i] : p_i          | -                      Riccati cost-to-go gradient, live-out only (LDS)
-    float a[N], b[N], c[N];
-    const size_t rowbase = ((size_t)inst * N) * 16 + r16;
+    //   a[i]  : g_i (x rows) | y_i (u rows)           duals                                (VGPR)
+    //   c[i]  : -(Xref_i.*Q) | d_i                    reference cost term | feed-forward   (VGPR)
+    //   b[i]  : v_i          | z_i                    previous slack                       (LDS)
+    //   sn[i] : vnew_i       | znew_i                 current slack                        (LDS)
+    // p_i (live-out only) is written to the pd array by every backward sweep together with d_i; the repeated
+    // overwrites of the same lines are absorbed by L2, only the last version reaches HBM.
+    float a[N], c[N];
+    // 32-bit element offset: lets the compiler address every array as SGPR base + one shared VGPR offset instead of
+    // keeping a 64-bit address pair per array alive through the loop (the host checks batch*N*16 < 2^30)
+    const int rowbase = (inst * N) * 16 + r16;
     int wstart = 0;
     if (P.xref_mode == 1 && valid) wstart = P.xref_start[inst];
-    const float *xref_p = P.xref + (size_t)inst * P.xref_inst_stride + r16;
+    const int xref_off = inst * (int)P.xref_inst_stride + r16;
     const bool cold = P.cold_start != 0;
     const bool zdual = cold || (P.duals_zero != 0);
     float xrN = 0.f; // Xref_{N-1}(r)
@@ -181,15 +184,14 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             {
                 int row = wstart + i;
                 row = row < P.table_rows ? row : P.table_rows - 1;
-                xr = P.xref_table[(size_t)row * 16 + r16];
+                xr = P.xref_table[row * 16 + r16];
             }
             else
-                xr = xref_p[(size_t)i * 16];
-            const float pd = cold ? 0.f : P.pd[rowbase + (size_t)i * 16];
+                xr = P.xref[xref_off + i * 16];
+            const float pd = cold ? 0.f : P.pd[rowbase + i * 16];
             c[i] = is_x ? -(xr * qrow) : pd;       // admm.cpp:81  q(i,j) = -(Xref(i,j) * Q(i))
-            if (i < N - 1) ps[i * WAVE] = is_x ? pd : 0.f;
-            b[i] = cold ? 0.f : P.vz[rowbase + (size_t)i * 16];
-            a[i] = zdual ? 0.f : P.gy[rowbase + (size_t)i * 16];
+            b[i * WAVE] = cold ? 0.f : P.vz[rowbase + i * 16];
+            a[i] = zdual ? 0.f : P.gy[rowbase + i * 16];
             sn[i * WAVE] = 0.f;
             if (i == N - 1) xrN = xr;
         }
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
         r_ds = P.res[4 * inst + 2]; r_di = P.res[4 * inst + 3];
     }
     float pN = 0.f; // p_{N-1} of the last executed forward sweep (x rows)
-    float *xu_out = P.xu + rowbase;
+    bool ran_bwd = false;
 
     // u_i and x_{i+1} from s = x_i (x rows); returns the stacked [x_i ; u_i] in sv
     auto lqr = [&](float s, float ci, float &sv, float &xn) {
@@ -257,10 +259,12 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             // ---------------- forward sweep: forward_pass + update_slack + update_dual + residual maxima ----------------
             float s = x0, pri = 0.f, dua = 0.f;
             float2 lh = bnd[r16];
+            float b_pref = b[0];
 #pragma unroll
             for (int i = 0; i < N; i++)
             {
-                const float2 lh_next = bnd[(i + 1 < N ? i + 1 : i) * 16 + r16]; // LDS read one step ahead
+                const float2 lh_next = bnd[(i + 1 < N ? i + 1 : i) * 16 + r16]; // LDS reads one step ahead
+                const float b_next = b[(i + 1 < N ? i + 1 : i) * WAVE];
                 float sv, xn = 0.f;
                 if (i < N - 1) lqr(s, c[i], sv, xn);
                 else sv = is_x ? s : 0.f;
@@ -270,11 +274,12 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
                 t = __builtin_amdgcn_fmed3f(t, lh.x, lh.y);
                 a[i] = (a[i] + sv) - t;                    // admm.cpp:69-70
                 pri = fmaxf(pri, fabsf(sv - t));           // admm.cpp:95,97
-                dua = fmaxf(dua, fabsf(b[i] - t));         // admm.cpp:96,98
+                dua = fmaxf(dua, fabsf(b_pref - t));       // admm.cpp:96,98
                 sn[i * WAVE] = t;
-                if (last_iter) xu_out[(size_t)i * 16] = sv; // x,u of an instance that exhausts max_iter
+                if (last_iter) P.xu[rowbase + i * 16] = sv; // x,u of an instance that exhausts max_iter
                 s = xn;
                 lh = lh_next;
+                b_pref = b_next;
                 __builtin_amdgcn_sched_barrier(0); // keep the steps apart (VGPR pressure)
             }
             {
@@ -301,7 +306,8 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             {
                 // ---------------- backward sweep: v=vnew, z=znew, linear cost, backward_pass_grad ----------------
                 float p = pN;
-                b[N - 1] = sn[(N - 1) * WAVE];
+                b[(N - 1) * WAVE] = sn[(N - 1) * WAVE];
+                ran_bwd = true;
                 float sn_pref = sn[(N - 2) * WAVE];
 #pragma unroll
                 for (int i = N - 2; i >= 0; i--)
@@ -336,8 +342,8 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
                         pn = acc;
                     }
                     c[i] = is_u ? dd : c[i];
-                    b[i] = sni;                            // admm.cpp:141-142
-                    ps[i * WAVE] = pn;
+                    b[i * WAVE] = sni;                     // admm.cpp:141-142
+                    P.pd[rowbase + i * 16] = is_u ? dd : pn; // [p_i ; d_i] of this sweep
                     p = pn;
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
 #pragma unroll
         for (int i = 0; i < N; i++)
         {
-            const size_t o = rowbase + (size_t)i * 16;
+            const int o = rowbase + i * 16;
             // x,u of a converged instance: regenerated from its frozen d by the same instruction sequence
             float sv, xn = 0.f;
             if (i < N - 1) lqr(s, c[i], sv, xn);
@@ -378,9 +384,12 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             if constexpr (EXACT) lin = cq - rho * t1;
             else lin = __builtin_fmaf(-rho, t1, cq);
             P.qr[o] = (i < N - 1 || is_x) ? lin : 0.f;
-            // p.col(N-1) is rewritten by every forward sweep (admm.cpp:83-84), the other columns by the backward sweeps
-            P.pd[o] = (i < N - 1) ? (is_x ? ps[(i < N - 1 ? i : 0) * WAVE] : c[i]) : (is_x ? pN : 0.f);
-            P.vz[o] = b[i];
+            // p.col(N-1) is rewritten by every forward sweep (admm.cpp:83-84); the other columns and d were stored by the
+            // last backward sweep this instance executed.  An instance that never ran one keeps its live-in p,d
+            // (all zero after reset_workspace, which only marked them so).
+            if (i == N - 1) P.pd[o] = is_x ? pN : 0.f;
+            else if (cold && !ran_bwd) P.pd[o] = 0.f;
+            P.vz[o] = b[i * WAVE];
             P.vzn[o] = sni;
             P.gy[o] = a[i];
             __builtin_amdgcn_sched_barrier(0);

@@ -646,7 +646,7 @@ int launch_solve(TinyBatch *tb)
         P.xref_mode = tb->xref_mode;
         P.xu = tb->pair[0]; P.qr = tb->pair[1]; P.pd = tb->pair[2]; P.vz = tb->pair[3]; P.vzn = tb->pair[4]; P.gy = tb->pair[5];
         P.xref = tb->r_xref;
-        P.xref_inst_stride = (tb->in_xref.set && !tb->in_xref.shared) ? (long long)tb->N * 16 : 0;
+        P.xref_inst_stride = (tb->in_xref.set && !tb->in_xref.shared) ? (unsigned)tb->N * 16u : 0u;
         P.xref_table = tb->tab_row; P.xref_start = tb->xref_start; P.table_rows = tb->table_rows;
         P.bounds = tb->r_bounds;
         P.mats = (v == VAR_ROW_EXACT) ? tb->mats_exact : tb->mats_fast;
@@ -694,7 +694,9 @@ int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int dev
     if (nx < 1 || nu < 1 || N < 2 || batch < 1)
         return fail(TINY_BATCH_EINVAL, "tiny_batch_create: need nx>=1, nu>=1, N>=2, batch>=1 (got %d,%d,%d,%d)", nx, nu, N, batch);
     const int nxc = (nx + 3) / 4, nuc = (nu + 3) / 4;
-    const bool tile_ok = stream_dims_supported(nxc, nuc), row_ok = rowlane_supported(nx, nu, N);
+    // the rowlane kernel addresses its arrays with 32-bit element offsets
+    const bool tile_ok = stream_dims_supported(nxc, nuc),
+               row_ok = rowlane_supported(nx, nu, N) && ((long long)(batch + 3) * N * 16 < (1ll << 30));
     if (!tile_ok && !row_ok)
         return fail(TINY_BATCH_EUNSUPPORTED,
                     "no kernel instantiation for nx=%d nu=%d N=%d; add it to TINY_FOR_EACH_DIMS / TINY_FOR_EACH_ROWLANE", nx, nu, N);

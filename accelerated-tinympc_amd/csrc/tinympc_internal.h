@@ -87,7 +87,7 @@ struct RowParams
     int xref_mode;               // 0: xref array (stride 0 = shared), 1: window gather
     float *xu, *qr, *pd, *vz, *vzn, *gy;
     const float *xref;           // [batch or 1][N][16]
-    long long xref_inst_stride;  // floats between instances (0 = shared)
+    unsigned xref_inst_stride;   // floats between instances (0 = shared)
     const float *xref_table;     // [rows][16]
     const int *xref_start;
     int table_rows;

@@ -62,8 +62,15 @@ for f in glob.glob(str(src / "stats" / "**" / "*kernel_stats.csv"), recursive=Tr
 # the table bench.py reads: "<kernel name>:<mode>:<batch>" -> HBM bytes per launch
 tf = prof / "hbm_traffic.json"
 table = json.loads(tf.read_text()) if tf.exists() else {}
+def label(kname):
+    import re
+    m = re.search(r"admm_rowlane_kernel<(\d+), (\d+), (\d+), (true|false)>", kname)
+    if m:
+        return f"rowlane<{m.group(1)},{m.group(2)},{m.group(3)},{'exact' if m.group(4) == 'true' else 'fast'}>"
+    m = re.search(r"admm_stream_kernel<(\d+), (\d+)>", kname)
+    return f"stream<{m.group(1)},{m.group(2)}>" if m else kname
 if line:
     for k, d in kern.items():
-        table[f"{line['roofline']['kernel']}:early_exit:{line['config']['instances_per_gpu']}"] = d["hbm_bytes"]
+        table[f"{label(k)}:early_exit:{line['config']['instances_per_gpu']}"] = d["hbm_bytes"]
 tf.write_text(json.dumps(table, indent=1))
 print(json.dumps({k: v for k, v in out.items() if k != "bench_line_under_profiler"}, indent=1)[:3000])
