@@ -17,7 +17,10 @@ CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libtinympc_hip.so"
 SOURCES = ["tinympc_batch.hip", "admm_stream.hip", "admm_rowlane.hip", "riccati.cpp"]
 HEADERS = [CSRC / "tinympc_internal.h", PKG.parent / "include" / "tinympc_batch.h"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-gpu-rdc"]
+# -ffp-contract=off : exact arithmetic must not fuse a*b+c; the fast paths call fma explicitly
+# -fno-slp-vectorize: hipcc otherwise pairs scalar fp32 adds into v_pk_add_f32 (+ v_mov to build the pairs), which on
+#                     gfx950 is slower than two plain v_add_f32 (measured, tools/micro/*.hip)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-gpu-rdc"]
 
 
 def _objs():

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
     const bool is_x = r16 < NX;
     const bool is_u = (r16 >= NX) && (r16 < NX + NU);
     const float rho = P.rho;
+    const float maskx = is_x ? 1.f : 0.f;
 
     // ---- box bounds of the whole horizon, shared by the batch: LDS table [N][16] of {lo, hi} ----
     __shared__ float2 bnd[N * 16];
@@ -233,7 +234,8 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             float acc;
             if constexpr (PL::FWD_U == PL::FWD_XA) acc = reduce<PL::FWD_XA>(t);
             else acc = is_x ? reduce<PL::FWD_XA>(t) : reduce<PL::FWD_U>(t);
-            const float un = (-acc) - ci;                 // u = -Kinf*x - d          (admm.cpp:31)
+            const float un = acc - ci;                    // u = -Kinf*x - d (admm.cpp:31); the u rows of M1 hold -Kinf,
+                                                          // negation is exact so this equals (-(K x)) - d bit for bit
             float t2[NU];
             dpp_products<NX, NU>(t2, un, M2);
             xn = acc + reduce<PL::FWD_XB>(t2);            // x' = Adyn*x + Bdyn*u     (admm.cpp:35)
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
                     const float sni = sn_pref;
                     sn_pref = sn[(i > 0 ? i - 1 : 0) * WAVE]; // LDS read one step ahead
                     const float t1 = sni - a[i];
-                    const float cq = is_x ? c[i] : 0.f;
+                    const float cq = c[i] * maskx;         // x rows: -(Xref.*Q) ; u rows: 0 (x*1 and d*0 are exact)
                     float pn, dd;
                     if constexpr (EXACT)
                     {
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             s = xn;
             const float sni = sn[i * WAVE];
             const float t1 = sni - a[i];
-            const float cq = is_x ? c[i] : 0.f;
+            const float cq = c[i] * maskx;
             float lin;
             if constexpr (EXACT) lin = cq - rho * t1;
             else lin = __builtin_fmaf(-rho, t1, cq);
