@@ -19,8 +19,7 @@
 //                  Eigen/src/Core/Redux.h, ProductEvaluators.h, GeneralProduct.h of the vendored Eigen 3.4.90).
 //                  Results are BITWISE identical to the compiled reference, iteration counts included.
 //   EXACT = false: one v_fmac_f32_dpp per multiply-add (k-ascending fma chain), ~2x fewer instructions.
-#include "tinympc_internal.h"
-#include "dpp_ops_gen.h"
+#include "rowlane_math.h"
 
 namespace tinympc
 {
@@ -30,96 +29,6 @@ namespace tinympc
 // so every chain is ONE generated inline-asm statement (tools/gen_dpp_ops.py).  A VALU write of `src`
 // followed by a DPP read of it needs two wait states which the compiler does not track inside asm: every
 // chain starts with s_nop 1.
-// ---------------------------------------------------------------------------------------------
-// Reduction orders of the reference build.  Eigen 3.4.90 picks them at compile time from storage order, sizes and
-// the SSE2 packet size (4 floats):
-//   SEQ  ((t0+t1)+t2)+...            packet-evaluated lazy products (result rows a multiple of 4: etor_product_packet_impl)
-//   TREE T(lo,n) = T(lo,n/2) + T(lo+n/2, n-n/2)   coefficient-evaluated, completely unrolled redux (redux_novec_unroller),
-//        taken while 3n-1 <= EIGEN_UNROLLING_LIMIT = 110, else SEQ
-//   VEC  products grouped in packets of 4, packets summed by the same halving tree (redux_vec_unroller), then
-//        predux (s0+s2)+(s1+s3), then the n%4 leftover (TREE) added; TREE when n < 4
-// The parity tests check the result bit for bit against vectors produced by the compiled reference.
-// ---------------------------------------------------------------------------------------------
-enum : int { PLAN_SEQ = 0, PLAN_TREE = 1, PLAN_VEC = 2 };
-constexpr int plan_novec(int n) { return (3 * n - 1 <= 110) ? PLAN_TREE : PLAN_SEQ; }
-constexpr int plan_vec(int n) { return n < 4 ? plan_novec(n) : PLAN_VEC; }
-
-template <int LO, int CNT, int NN>
-__device__ __forceinline__ float tree_sum(const float (&t)[NN])
-{
-    if constexpr (CNT == 1) return t[LO];
-    else
-    {
-        constexpr int H = CNT / 2;
-        return tree_sum<LO, H>(t) + tree_sum<LO + H, CNT - H>(t);
-    }
-}
-template <int PLO, int PCNT, int L, int NN>
-__device__ __forceinline__ float ptree_sum(const float (&t)[NN]) // lane L of the packets [PLO, PLO+PCNT)
-{
-    if constexpr (PCNT == 1) return t[4 * PLO + L];
-    else
-    {
-        constexpr int H = PCNT / 2;
-        return ptree_sum<PLO, H, L>(t) + ptree_sum<PLO + H, PCNT - H, L>(t);
-    }
-}
-template <int PLAN, int NN>
-__device__ __forceinline__ float reduce(const float (&t)[NN])
-{
-    if constexpr (NN == 1) return t[0];
-    else if constexpr (PLAN == PLAN_SEQ)
-    {
-        float acc = t[0];
-#pragma unroll
-        for (int k = 1; k < NN; k++) acc = acc + t[k];
-        return acc;
-    }
-    else if constexpr (PLAN == PLAN_TREE) return tree_sum<0, NN>(t);
-    else
-    {
-        constexpr int NPK = NN / 4;
-        const float s0 = ptree_sum<0, NPK, 0>(t), s1 = ptree_sum<0, NPK, 1>(t), s2 = ptree_sum<0, NPK, 2>(t),
-                    s3 = ptree_sum<0, NPK, 3>(t);
-        float res = (s0 + s2) + (s1 + s3); // SSE2 predux
-        if constexpr (NN % 4 != 0) res = res + tree_sum<4 * NPK, NN - 4 * NPK>(t);
-        return res;
-    }
-}
-
-// max over the 16 lanes of a DPP row; every lane gets the result
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float row_max(float v)
-{
-    v = fmaxf(v, dpp_mov<0x128>(v)); // row_ror:8
-    v = fmaxf(v, dpp_mov<0x124>(v)); // row_ror:4
-    v = fmaxf(v, dpp_mov<0x122>(v)); // row_ror:2
-    v = fmaxf(v, dpp_mov<0x121>(v)); // row_ror:1
-    return v;
-}
-
-template <int NX, int NU>
-struct RowPlans
-{
-    static_assert(NX > 1 && NU >= 1 && NX + NU <= 16, "rowlane kernel needs 1 < nx, nx + nu <= 16");
-    static_assert(!(NU >= 8 && NX >= 8), "Eigen switches to its GEMV kernel there; not restated");
-    // forward_pass (admm.cpp:31,35)
-    static constexpr int FWD_U = (NU > 1 && NU % 4 == 0) ? PLAN_SEQ : (NU == 1 ? plan_vec(NX) : plan_novec(NX));
-    static constexpr int FWD_XA = (NX % 4 == 0) ? PLAN_SEQ : plan_novec(NX);
-    static constexpr int FWD_XB = (NX % 4 == 0) ? PLAN_SEQ : plan_novec(NU);
-    // update_linear_cost terminal term (admm.cpp:83)
-    static constexpr int TERM = plan_vec(NX);
-    // backward_pass_grad (admm.cpp:19-20)
-    static constexpr int BWD_TMP = plan_vec(NX);
-    static constexpr int BWD_D = (NU > 1 && NU % 4 == 0) ? PLAN_SEQ : plan_novec(NU);
-    static constexpr int BWD_PA = (NU == 1 && NX % 4 == 0) ? PLAN_SEQ : plan_novec(NX);
-    static constexpr int BWD_PK = plan_vec(NU);
-};
-
 template <int NX, int NU, int N, bool EXACT>
 __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P)
 {
@@ -145,18 +54,8 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
     float *b = b_lds + lane;     // b[i * WAVE]
 
     // ---- gain rows of this lane -----------------------------------------------------------------
-    float M1[NX], M2[NU], M3[NX], M45[NU];
-    {
-        const float *m = P.mats + r16;
-#pragma unroll
-        for (int k = 0; k < NX; k++) M1[k] = m[(k) * 16];
-#pragma unroll
-        for (int k = 0; k < NU; k++) M2[k] = m[(NX + k) * 16];
-#pragma unroll
-        for (int k = 0; k < NX; k++) M3[k] = m[(NX + NU + k) * 16];
-#pragma unroll
-        for (int k = 0; k < NU; k++) M45[k] = m[(2 * NX + NU + k) * 16];
-    }
+    RowGains<NX, NU> G;
+    G.load(P.mats, r16);
 
     // ---- per-instance state, all in registers --------------------------------------------------------
     //   a[i]  : g_i (x rows) | y_i (u rows)           duals                                (VGPR)
@@ -200,20 +99,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
     const float x0 = P.xu[rowbase]; // x.col(0) on x rows (u rows hold stale u_0, never used as x)
 
     // -(Xref_{N-1}^T Pinf): constant during a solve (admm.cpp:83)
-    float pterm;
-    {
-        float PT[NX];
-#pragma unroll
-        for (int k = 0; k < NX; k++) PT[k] = P.mats[(2 * NX + 2 * NU + 1 + k) * 16 + r16]; // Pinf(k, r)
-        if constexpr (EXACT)
-        {
-            float t[NX];
-            dpp_products<0, NX>(t, xrN, PT);
-            pterm = -reduce<PL::TERM>(t);
-        }
-        else
-            pterm = -dpp_fma_dot<0, NX>(xrN, PT);
-    }
+    const float pterm = terminal_term<NX, NU, EXACT>(P.mats, r16, xrN);
 
     int st = TINY_STATUS_UNSOLVED_, itn = 1; // admm.cpp:114-115
     float r_ps = 0.f, r_pi = 0.f, r_ds = 0.f, r_di = 0.f;
@@ -225,31 +111,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
     float pN = 0.f; // p_{N-1} of the last executed forward sweep (x rows)
     bool ran_bwd = false;
 
-    // u_i and x_{i+1} from s = x_i (x rows); returns the stacked [x_i ; u_i] in sv
-    auto lqr = [&](float s, float ci, float &sv, float &xn) {
-        if constexpr (EXACT)
-        {
-            float t[NX];
-            dpp_products<0, NX>(t, s, M1);
-            float acc;
-            if constexpr (PL::FWD_U == PL::FWD_XA) acc = reduce<PL::FWD_XA>(t);
-            else acc = is_x ? reduce<PL::FWD_XA>(t) : reduce<PL::FWD_U>(t);
-            const float un = acc - ci;                    // u = -Kinf*x - d (admm.cpp:31); the u rows of M1 hold -Kinf,
-                                                          // negation is exact so this equals (-(K x)) - d bit for bit
-            float t2[NU];
-            dpp_products<NX, NU>(t2, un, M2);
-            xn = acc + reduce<PL::FWD_XB>(t2);            // x' = Adyn*x + Bdyn*u     (admm.cpp:35)
-            sv = is_u ? un : s;
-        }
-        else
-        {
-            float acc = dpp_fma_dot<0, NX>(s, M1);        // u rows carry -Kinf
-            const float un = acc - ci;
-            dpp_fma_acc<NX, NU>(acc, un, M2);
-            xn = acc;
-            sv = is_u ? un : s;
-        }
-    };
+    auto lqr = [&](float s_, float ci, float &sv, float &xn) { lqr_step<NX, NU, EXACT>(G, is_x, is_u, s_, ci, sv, xn); };
 
     bool active = valid && (P.max_iter > 0);
     for (int it = 0; it < P.max_iter; ++it)
@@ -286,8 +148,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             }
             {
                 const float t1 = sn[(N - 1) * WAVE] - a[N - 1];
-                if constexpr (EXACT) pN = pterm - rho * t1; // admm.cpp:83-84
-                else pN = __builtin_fmaf(-rho, t1, pterm);
+                pN = lin_cost<EXACT>(pterm, rho, t1); // admm.cpp:83-84
             }
             // ---------------- termination_condition (admm.cpp:91-109) ----------------
             const float pri_x = row_max(is_x ? pri : 0.f), dua_x = row_max(is_x ? dua : 0.f);
@@ -319,30 +180,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
                     const float t1 = sni - a[i];
                     const float cq = c[i] * maskx;         // x rows: -(Xref.*Q) ; u rows: 0 (x*1 and d*0 are exact)
                     float pn, dd;
-                    if constexpr (EXACT)
-                    {
-                        const float lin = cq - rho * t1;   // x rows: q_i (admm.cpp:81-82) | u rows: r_i (admm.cpp:80)
-                        float t[NX];
-                        dpp_products<0, NX>(t, p, M3);
-                        float dot;
-                        if constexpr (PL::BWD_PA == PL::BWD_TMP) dot = reduce<PL::BWD_PA>(t);
-                        else dot = is_x ? reduce<PL::BWD_PA>(t) : reduce<PL::BWD_TMP>(t);
-                        const float wv = lin + dot;        // q + AmBKt*p  |  Bdyn^T*p + r
-                        float tk[NU], td[NU];
-                        dpp_products<NX, NU>(tk, lin, M45); // Kinf^T * r
-                        dpp_products<NX, NU>(td, wv, M45);  // Quu_inv * (Bdyn^T p + r)
-                        pn = wv - reduce<PL::BWD_PK>(tk);  // admm.cpp:20
-                        dd = reduce<PL::BWD_D>(td);        // admm.cpp:19
-                    }
-                    else
-                    {
-                        float acc = __builtin_fmaf(-rho, t1, cq);
-                        const float lin = acc;
-                        dpp_fma_acc<0, NX>(acc, p, M3);
-                        dd = dpp_fma_dot<NX, NU>(acc, M45); // u rows: Quu_inv
-                        dpp_fma_acc<NX, NU>(acc, lin, M45); // x rows: -Kinf^T
-                        pn = acc;
-                    }
+                    riccati_step<NX, NU, EXACT>(G, is_x, p, lin_cost<EXACT>(cq, rho, t1), pn, dd); // admm.cpp:19-20,80-82
                     c[i] = is_u ? dd : c[i];
                     b[i * WAVE] = sni;                     // admm.cpp:141-142
                     P.pd[rowbase + i * 16] = is_u ? dd : pn; // [p_i ; d_i] of this sweep
@@ -382,9 +220,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             const float sni = sn[i * WAVE];
             const float t1 = sni - a[i];
             const float cq = c[i] * maskx;
-            float lin;
-            if constexpr (EXACT) lin = cq - rho * t1;
-            else lin = __builtin_fmaf(-rho, t1, cq);
+            const float lin = lin_cost<EXACT>(cq, rho, t1);
             P.qr[o] = (i < N - 1 || is_x) ? lin : 0.f;
             // p.col(N-1) is rewritten by every forward sweep (admm.cpp:83-84); the other columns and d were stored by the
             // last backward sweep this instance executed.  An instance that never ran one keeps its live-in p,d

@@ -1,0 +1,146 @@
+// admm_steps.hip — batched twins of the six step functions the reference exports next to tiny_solve()
+// (src/tinympc/admm.hpp:10-18): forward_pass, update_slack, update_dual, update_linear_cost, termination_condition,
+// backward_pass_grad.  Each is one launch over the row layout (one DPP row of 16 lanes = one instance, any horizon N,
+// nx + nu <= 16) that reads and writes the device-resident workspace exactly as the reference function reads and writes
+// TinyWorkspace.  They share the arithmetic of the fused solver (rowlane_math.h), so in exact mode each function is
+// bit-identical to the reference's.  The fused kernels do not call these; they exist for callers that drive the
+// algorithm step by step (e.g. only roll out a trajectory with forward_pass).
+#include "rowlane_math.h"
+
+namespace tinympc
+{
+
+template <int NX, int NU, bool EXACT>
+__global__ __launch_bounds__(WAVE) void admm_step_kernel(const RowParams P, const int fn, int *__restrict__ conv_out)
+{
+    const int lane = threadIdx.x, r16 = lane & 15;
+    const int inst = blockIdx.x * 4 + (lane >> 4);
+    const bool valid = inst < P.batch;
+    const bool is_x = r16 < NX, is_u = (r16 >= NX) && (r16 < NX + NU);
+    const int N = P.N;
+    const int rowbase = (inst * N) * 16 + r16;
+    const float rho = P.rho;
+
+    if (fn == STEP_FORWARD_PASS) // admm.cpp:27-37  reads x.col(0), d; writes u, x.col(1..N-1)
+    {
+        RowGains<NX, NU> G;
+        G.load(P.mats, r16);
+        float s = P.xu[rowbase];
+        for (int i = 0; i < N - 1; i++)
+        {
+            float sv, xn;
+            lqr_step<NX, NU, EXACT>(G, is_x, is_u, s, P.pd[rowbase + i * 16], sv, xn);
+            if (valid) P.xu[rowbase + i * 16] = sv;
+            s = xn;
+        }
+        if (valid) P.xu[rowbase + (N - 1) * 16] = is_x ? s : 0.f;
+    }
+    else if (fn == STEP_UPDATE_SLACK) // admm.cpp:45-61  znew = clip(u + y), vnew = clip(x + g)
+    {
+        const float2 *bnd = reinterpret_cast<const float2 *>(P.bounds);
+        for (int i = 0; i < N; i++)
+        {
+            const float2 lh = bnd[i * 16 + r16];
+            const float t = P.xu[rowbase + i * 16] + P.gy[rowbase + i * 16];
+            if (valid) P.vzn[rowbase + i * 16] = __builtin_amdgcn_fmed3f(t, lh.x, lh.y);
+        }
+    }
+    else if (fn == STEP_UPDATE_DUAL) // admm.cpp:67-71  y += u - znew, g += x - vnew
+    {
+        for (int i = 0; i < N; i++)
+        {
+            const float a = P.gy[rowbase + i * 16];
+            if (valid) P.gy[rowbase + i * 16] = (a + P.xu[rowbase + i * 16]) - P.vzn[rowbase + i * 16];
+        }
+    }
+    else if (fn == STEP_UPDATE_LINEAR_COST) // admm.cpp:77-85  r, q, p.col(N-1)
+    {
+        const float qrow = P.mats[(2 * NX + 2 * NU) * 16 + r16];
+        int wstart = 0;
+        if (P.xref_mode == 1 && valid) wstart = P.xref_start[inst];
+        const int xref_off = inst * (int)P.xref_inst_stride + r16;
+        float xr = 0.f, t1 = 0.f;
+        for (int i = 0; i < N; i++)
+        {
+            if (P.xref_mode == 1)
+            {
+                int row = wstart + i;
+                row = row < P.table_rows ? row : P.table_rows - 1;
+                xr = P.xref_table[row * 16 + r16];
+            }
+            else
+                xr = P.xref[xref_off + i * 16];
+            const float cq = is_x ? -(xr * qrow) : 0.f;
+            t1 = P.vzn[rowbase + i * 16] - P.gy[rowbase + i * 16];
+            const float lin = lin_cost<EXACT>(cq, rho, t1);
+            if (valid) P.qr[rowbase + i * 16] = (i < N - 1 || is_x) ? lin : 0.f;
+        }
+        const float pterm = terminal_term<NX, NU, EXACT>(P.mats, r16, xr); // xr, t1 are those of step N-1 here
+        if (valid && is_x) P.pd[rowbase + (N - 1) * 16] = lin_cost<EXACT>(pterm, rho, t1);
+    }
+    else if (fn == STEP_TERMINATION_CONDITION) // admm.cpp:91-109  residual fields + the boolean it returns
+    {
+        bool conv = false;
+        const int itn = valid ? P.iter[inst] : 1;
+        if (itn % P.check_termination == 0) // row-uniform
+        {
+            float pri = 0.f, dua = 0.f;
+            for (int i = 0; i < N; i++)
+            {
+                const float sv = P.xu[rowbase + i * 16], t = P.vzn[rowbase + i * 16];
+                pri = fmaxf(pri, fabsf(sv - t));
+                dua = fmaxf(dua, fabsf(P.vz[rowbase + i * 16] - t));
+            }
+            const float r_ps = row_max(is_x ? pri : 0.f), r_ds = row_max(is_x ? dua : 0.f) * rho;
+            const float r_pi = row_max(is_u ? pri : 0.f), r_di = row_max(is_u ? dua : 0.f) * rho;
+            conv = (r_ps < P.abs_pri_tol) && (r_pi < P.abs_pri_tol) && (r_ds < P.abs_dua_tol) && (r_di < P.abs_dua_tol);
+            if (valid && r16 == 0)
+            {
+                P.res[4 * inst + 0] = r_ps; P.res[4 * inst + 1] = r_pi;
+                P.res[4 * inst + 2] = r_ds; P.res[4 * inst + 3] = r_di;
+            }
+        }
+        if (valid && r16 == 0)
+        {
+            conv_out[inst] = conv ? 1 : 0;
+            if (!conv) atomicAdd(P.n_unsolved, 1);
+        }
+    }
+    else if (fn == STEP_BACKWARD_PASS_GRAD) // admm.cpp:15-22  reads p.col(N-1), q, r; writes d, p.col(0..N-2)
+    {
+        RowGains<NX, NU> G;
+        G.load(P.mats, r16);
+        float p = P.pd[rowbase + (N - 1) * 16];
+        for (int i = N - 2; i >= 0; i--)
+        {
+            float pn, dd;
+            riccati_step<NX, NU, EXACT>(G, is_x, p, P.qr[rowbase + i * 16], pn, dd);
+            if (valid) P.pd[rowbase + i * 16] = is_u ? dd : pn;
+            p = pn;
+        }
+    }
+}
+
+bool rowdims_supported(int nx, int nu)
+{
+#define TINY_ROWDIMS_CHECK(NX, NU) \
+    if (nx == NX && nu == NU) return true;
+    TINY_FOR_EACH_ROWDIMS(TINY_ROWDIMS_CHECK)
+    return false;
+}
+
+hipError_t launch_admm_step(int nx, int nu, bool exact, int fn, const RowParams &P, int *conv_out, hipStream_t stream)
+{
+    const int nblocks = (P.batch + 3) / 4;
+#define TINY_ROWDIMS_DISPATCH(NX, NU)                                                                                       \
+    if (nx == NX && nu == NU)                                                                                               \
+    {                                                                                                                       \
+        if (exact) hipLaunchKernelGGL((admm_step_kernel<NX, NU, true>), dim3(nblocks), dim3(WAVE), 0, stream, P, fn, conv_out);  \
+        else hipLaunchKernelGGL((admm_step_kernel<NX, NU, false>), dim3(nblocks), dim3(WAVE), 0, stream, P, fn, conv_out); \
+        return hipGetLastError();                                                                                           \
+    }
+    TINY_FOR_EACH_ROWDIMS(TINY_ROWDIMS_DISPATCH)
+    return hipErrorInvalidValue;
+}
+
+} // namespace tinympc

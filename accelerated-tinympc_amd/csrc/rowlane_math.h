@@ -1,0 +1,206 @@
+// rowlane_math.h — per-step arithmetic of the "row lane" mapping (one DPP row of 16 lanes = one instance; lane r owns
+// row r of the stacked vector [x ; u]), shared by the register-resident solver (admm_rowlane.hip) and the single-function
+// kernels (admm_steps.hip).  See admm_rowlane.hip for the mapping and the two arithmetic modes.
+#pragma once
+#include "tinympc_internal.h"
+#include "dpp_ops_gen.h"
+
+namespace tinympc
+{
+
+// ---------------------------------------------------------------------------------------------
+// Reduction orders of the reference build.  Eigen 3.4.90 picks them at compile time from storage order, sizes and
+// the SSE2 packet size (4 floats):
+//   SEQ  ((t0+t1)+t2)+...            packet-evaluated lazy products (result rows a multiple of 4: etor_product_packet_impl)
+//   TREE T(lo,n) = T(lo,n/2) + T(lo+n/2, n-n/2)   coefficient-evaluated, completely unrolled redux (redux_novec_unroller),
+//        taken while 3n-1 <= EIGEN_UNROLLING_LIMIT = 110, else SEQ
+//   VEC  products grouped in packets of 4, packets summed by the same halving tree (redux_vec_unroller), then
+//        predux (s0+s2)+(s1+s3), then the n%4 leftover (TREE) added; TREE when n < 4
+// The parity tests check the result bit for bit against vectors produced by the compiled reference.
+// ---------------------------------------------------------------------------------------------
+enum : int { PLAN_SEQ = 0, PLAN_TREE = 1, PLAN_VEC = 2 };
+constexpr int plan_novec(int n) { return (3 * n - 1 <= 110) ? PLAN_TREE : PLAN_SEQ; }
+constexpr int plan_vec(int n) { return n < 4 ? plan_novec(n) : PLAN_VEC; }
+
+template <int LO, int CNT, int NN>
+__device__ __forceinline__ float tree_sum(const float (&t)[NN])
+{
+    if constexpr (CNT == 1) return t[LO];
+    else
+    {
+        constexpr int H = CNT / 2;
+        return tree_sum<LO, H>(t) + tree_sum<LO + H, CNT - H>(t);
+    }
+}
+template <int PLO, int PCNT, int L, int NN>
+__device__ __forceinline__ float ptree_sum(const float (&t)[NN]) // lane L of the packets [PLO, PLO+PCNT)
+{
+    if constexpr (PCNT == 1) return t[4 * PLO + L];
+    else
+    {
+        constexpr int H = PCNT / 2;
+        return ptree_sum<PLO, H, L>(t) + ptree_sum<PLO + H, PCNT - H, L>(t);
+    }
+}
+template <int PLAN, int NN>
+__device__ __forceinline__ float reduce(const float (&t)[NN])
+{
+    if constexpr (NN == 1) return t[0];
+    else if constexpr (PLAN == PLAN_SEQ)
+    {
+        float acc = t[0];
+#pragma unroll
+        for (int k = 1; k < NN; k++) acc = acc + t[k];
+        return acc;
+    }
+    else if constexpr (PLAN == PLAN_TREE) return tree_sum<0, NN>(t);
+    else
+    {
+        constexpr int NPK = NN / 4;
+        const float s0 = ptree_sum<0, NPK, 0>(t), s1 = ptree_sum<0, NPK, 1>(t), s2 = ptree_sum<0, NPK, 2>(t),
+                    s3 = ptree_sum<0, NPK, 3>(t);
+        float res = (s0 + s2) + (s1 + s3); // SSE2 predux
+        if constexpr (NN % 4 != 0) res = res + tree_sum<4 * NPK, NN - 4 * NPK>(t);
+        return res;
+    }
+}
+
+// max over the 16 lanes of a DPP row; every lane gets the result
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_max(float v)
+{
+    v = fmaxf(v, dpp_mov<0x128>(v)); // row_ror:8
+    v = fmaxf(v, dpp_mov<0x124>(v)); // row_ror:4
+    v = fmaxf(v, dpp_mov<0x122>(v)); // row_ror:2
+    v = fmaxf(v, dpp_mov<0x121>(v)); // row_ror:1
+    return v;
+}
+
+template <int NX, int NU>
+struct RowPlans
+{
+    static_assert(NX > 1 && NU >= 1 && NX + NU <= 16, "rowlane kernel needs 1 < nx, nx + nu <= 16");
+    static_assert(!(NU >= 8 && NX >= 8), "Eigen switches to its GEMV kernel there; not restated");
+    // forward_pass (admm.cpp:31,35)
+    static constexpr int FWD_U = (NU > 1 && NU % 4 == 0) ? PLAN_SEQ : (NU == 1 ? plan_vec(NX) : plan_novec(NX));
+    static constexpr int FWD_XA = (NX % 4 == 0) ? PLAN_SEQ : plan_novec(NX);
+    static constexpr int FWD_XB = (NX % 4 == 0) ? PLAN_SEQ : plan_novec(NU);
+    // update_linear_cost terminal term (admm.cpp:83)
+    static constexpr int TERM = plan_vec(NX);
+    // backward_pass_grad (admm.cpp:19-20)
+    static constexpr int BWD_TMP = plan_vec(NX);
+    static constexpr int BWD_D = (NU > 1 && NU % 4 == 0) ? PLAN_SEQ : plan_novec(NU);
+    static constexpr int BWD_PA = (NU == 1 && NX % 4 == 0) ? PLAN_SEQ : plan_novec(NX);
+    static constexpr int BWD_PK = plan_vec(NU);
+};
+
+// Gain rows of one lane (packed by the host, tinympc_batch.hip: pack_gains):
+//   M1[k]  x rows A(r,k)      | u rows -K(m,k)            M2[m]  x rows B(r,m) | u rows 0
+//   M3[k]  x rows AmBKt(r,k)  | u rows  B(k,m)            M45[m] x rows K(m,r) (exact) / -K(m,r) (fast) | u rows Quu_inv(mr,m)
+template <int NX, int NU>
+struct RowGains
+{
+    float M1[NX], M2[NU], M3[NX], M45[NU];
+    __device__ __forceinline__ void load(const float *mats, int r16)
+    {
+        const float *m = mats + r16;
+#pragma unroll
+        for (int k = 0; k < NX; k++) M1[k] = m[(k) * 16];
+#pragma unroll
+        for (int k = 0; k < NU; k++) M2[k] = m[(NX + k) * 16];
+#pragma unroll
+        for (int k = 0; k < NX; k++) M3[k] = m[(NX + NU + k) * 16];
+#pragma unroll
+        for (int k = 0; k < NU; k++) M45[k] = m[(2 * NX + NU + k) * 16];
+    }
+};
+
+// forward_pass step (admm.cpp:31,35): from s = x_i (x rows) and ci = d_i (u rows) compute
+//   sv = [x_i ; u_i]  with u_i = -Kinf*x_i - d_i,   xn = x_{i+1} = Adyn*x_i + Bdyn*u_i (x rows)
+template <int NX, int NU, bool EXACT>
+__device__ __forceinline__ void lqr_step(const RowGains<NX, NU> &G, bool is_x, bool is_u, float s, float ci, float &sv, float &xn)
+{
+    using PL = RowPlans<NX, NU>;
+    if constexpr (EXACT)
+    {
+        float t[NX];
+        dpp_products<0, NX>(t, s, G.M1);
+        float acc;
+        if constexpr (PL::FWD_U == PL::FWD_XA) acc = reduce<PL::FWD_XA>(t);
+        else acc = is_x ? reduce<PL::FWD_XA>(t) : reduce<PL::FWD_U>(t);
+        const float un = acc - ci; // the u rows of M1 hold -Kinf; negation is exact, so this is (-(K x)) - d bit for bit
+        float t2[NU];
+        dpp_products<NX, NU>(t2, un, G.M2);
+        xn = acc + reduce<PL::FWD_XB>(t2);
+        sv = is_u ? un : s;
+    }
+    else
+    {
+        float acc = dpp_fma_dot<0, NX>(s, G.M1);
+        const float un = acc - ci;
+        dpp_fma_acc<NX, NU>(acc, un, G.M2);
+        xn = acc;
+        sv = is_u ? un : s;
+    }
+}
+
+// backward_pass_grad step (admm.cpp:19-20): from p = p_{i+1} (x rows) and lin = [q_i ; r_i] compute
+//   pn = p_i = q_i + AmBKt*p_{i+1} - Kinf^T*r_i (x rows),   dd = d_i = Quu_inv*(Bdyn^T*p_{i+1} + r_i) (u rows)
+template <int NX, int NU, bool EXACT>
+__device__ __forceinline__ void riccati_step(const RowGains<NX, NU> &G, bool is_x, float p, float lin, float &pn, float &dd)
+{
+    using PL = RowPlans<NX, NU>;
+    if constexpr (EXACT)
+    {
+        float t[NX];
+        dpp_products<0, NX>(t, p, G.M3);
+        float dot;
+        if constexpr (PL::BWD_PA == PL::BWD_TMP) dot = reduce<PL::BWD_PA>(t);
+        else dot = is_x ? reduce<PL::BWD_PA>(t) : reduce<PL::BWD_TMP>(t);
+        const float wv = lin + dot;            // q + AmBKt*p  |  Bdyn^T*p + r
+        float tk[NU], td[NU];
+        dpp_products<NX, NU>(tk, lin, G.M45);  // Kinf^T * r
+        dpp_products<NX, NU>(td, wv, G.M45);   // Quu_inv * (Bdyn^T p + r)
+        pn = wv - reduce<PL::BWD_PK>(tk);
+        dd = reduce<PL::BWD_D>(td);
+    }
+    else
+    {
+        float acc = lin;
+        dpp_fma_acc<0, NX>(acc, p, G.M3);
+        dd = dpp_fma_dot<NX, NU>(acc, G.M45);  // u rows: Quu_inv
+        dpp_fma_acc<NX, NU>(acc, lin, G.M45);  // x rows: -Kinf^T
+        pn = acc;
+    }
+}
+
+// [q_i ; r_i] of update_linear_cost (admm.cpp:80-82): cq = -(Xref_i .* Q) on x rows and 0 on u rows, t1 = snew - dual
+template <bool EXACT>
+__device__ __forceinline__ float lin_cost(float cq, float rho, float t1)
+{
+    if constexpr (EXACT) return cq - rho * t1;
+    else return __builtin_fmaf(-rho, t1, cq);
+}
+
+// -(Xref_{N-1}^T Pinf) (admm.cpp:83), x rows; PT[k] = Pinf(k, r)
+template <int NX, int NU, bool EXACT>
+__device__ __forceinline__ float terminal_term(const float *mats, int r16, float xrN)
+{
+    float PT[NX];
+#pragma unroll
+    for (int k = 0; k < NX; k++) PT[k] = mats[(2 * NX + 2 * NU + 1 + k) * 16 + r16];
+    if constexpr (EXACT)
+    {
+        float t[NX];
+        dpp_products<0, NX>(t, xrN, PT);
+        return -reduce<RowPlans<NX, NU>::TERM>(t);
+    }
+    else
+        return -dpp_fma_dot<0, NX>(xrN, PT);
+}
+
+} // namespace tinympc

@@ -179,7 +179,8 @@ struct TinyBatch
 {
     int nx = 0, nu = 0, N = 0, batch = 0, device = 0;
     int NXC = 0, NUC = 0, ntiles = 0, bpad4 = 0;
-    bool row_dims_ok = false, tile_dims_ok = false;
+    bool row_dims_ok = false, tile_dims_ok = false, rowmath_ok = false;
+    int *conv_dev = nullptr; // [batch] result of termination_condition
     hipStream_t stream = nullptr;
     // problem class
     bool have_cache = false, have_dyn = false, have_settings = false, gains_dirty = true;
@@ -462,7 +463,7 @@ int pack_gains(TinyBatch *tb)
         TRY(upload_vec(tb, &tb->opnd, o));
         TRY(upload_vec(tb, &tb->qvec, qv));
     }
-    if (tb->row_dims_ok)
+    if (tb->rowmath_ok)
     {
         // ---- gains for the rowlane kernel: [3nx + 2nu + 1][16], entry (reg, r) = the value lane r of a row holds.
         //   M1[k]  (k<nx): x rows A(r,k)      | u rows -K(m,k)
@@ -588,6 +589,55 @@ void update_kname(TinyBatch *tb)
     tb->kname = nm;
 }
 
+void fill_row_params(TinyBatch *tb, RowParams &P, bool exact)
+{
+    P.nx = tb->nx; P.nu = tb->nu; P.N = tb->N; P.batch = tb->batch;
+    P.rho = tb->rho; P.abs_pri_tol = tb->abs_pri_tol; P.abs_dua_tol = tb->abs_dua_tol;
+    P.max_iter = tb->max_iter; P.check_termination = tb->check_termination;
+    P.duals_zero = tb->duals_zero_pending ? 1 : 0;
+    P.cold_start = tb->cold_pending ? 1 : 0;
+    P.xref_mode = tb->xref_mode;
+    P.xu = tb->pair[0]; P.qr = tb->pair[1]; P.pd = tb->pair[2]; P.vz = tb->pair[3]; P.vzn = tb->pair[4]; P.gy = tb->pair[5];
+    P.xref = tb->r_xref;
+    P.xref_inst_stride = (tb->in_xref.set && !tb->in_xref.shared) ? (unsigned)tb->N * 16u : 0u;
+    P.xref_table = tb->tab_row; P.xref_start = tb->xref_start; P.table_rows = tb->table_rows;
+    P.bounds = tb->r_bounds;
+    P.mats = exact ? tb->mats_exact : tb->mats_fast;
+    P.res = tb->res; P.status = tb->status; P.iter = tb->iter; P.n_unsolved = tb->n_unsolved;
+}
+
+// One of the six step functions of admm.hpp:10-18 over the whole batch (admm_steps.hip).
+int run_step(TinyBatch *tb, int fn, int *converged_host, int *n_true)
+{
+    if (!tb->have_cache || !tb->have_dyn || !tb->have_settings)
+        return fail(TINY_BATCH_ENOTREADY, "set_cache, set_dynamics and set_settings must be called first");
+    if (!tb->rowmath_ok)
+        return fail(TINY_BATCH_EUNSUPPORTED, "the single-function kernels need nx + nu <= 16 and an entry in TINY_FOR_EACH_ROWDIMS (nx=%d nu=%d)", tb->nx, tb->nu);
+    if (fn == STEP_UPDATE_SLACK && !bounds_all_shared(tb))
+        return fail(TINY_BATCH_EUNSUPPORTED, "update_slack as a separate call needs batch-shared bounds");
+    TRY(set_device(tb));
+    if (tb->gains_dirty) TRY(pack_gains(tb));
+    TRY(ensure_layout(tb, LAYOUT_ROW));
+    TRY(prepare_inputs(tb, LAYOUT_ROW));
+    TRY(flush_pending(tb));
+    if (!tb->conv_dev) TRY(dev_alloc_zero((float **)&tb->conv_dev, tb->batch));
+    RowParams P;
+    fill_row_params(tb, P, tb->variant != VAR_ROW_FAST);
+    HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, sizeof(int), tb->stream));
+    hipError_t e = launch_admm_step(tb->nx, tb->nu, tb->variant != VAR_ROW_FAST, fn, P, tb->conv_dev, tb->stream);
+    if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    if (fn == STEP_TERMINATION_CONDITION)
+    {
+        int n_false = 0;
+        HIP_TRY(hipMemcpyAsync(&n_false, tb->n_unsolved, sizeof(int), hipMemcpyDeviceToHost, tb->stream));
+        if (converged_host)
+            HIP_TRY(hipMemcpyAsync(converged_host, tb->conv_dev, (size_t)tb->batch * sizeof(int), hipMemcpyDeviceToHost, tb->stream));
+        HIP_TRY(hipStreamSynchronize(tb->stream));
+        if (n_true) *n_true = tb->batch - n_false;
+    }
+    return 0;
+}
+
 int launch_solve(TinyBatch *tb)
 {
     if (!tb->have_cache || !tb->have_dyn || !tb->have_settings)
@@ -638,19 +688,7 @@ int launch_solve(TinyBatch *tb)
     else
     {
         RowParams P;
-        P.nx = tb->nx; P.nu = tb->nu; P.N = tb->N; P.batch = tb->batch;
-        P.rho = tb->rho; P.abs_pri_tol = tb->abs_pri_tol; P.abs_dua_tol = tb->abs_dua_tol;
-        P.max_iter = tb->max_iter; P.check_termination = tb->check_termination;
-        P.duals_zero = tb->duals_zero_pending ? 1 : 0;
-        P.cold_start = tb->cold_pending ? 1 : 0;
-        P.xref_mode = tb->xref_mode;
-        P.xu = tb->pair[0]; P.qr = tb->pair[1]; P.pd = tb->pair[2]; P.vz = tb->pair[3]; P.vzn = tb->pair[4]; P.gy = tb->pair[5];
-        P.xref = tb->r_xref;
-        P.xref_inst_stride = (tb->in_xref.set && !tb->in_xref.shared) ? (unsigned)tb->N * 16u : 0u;
-        P.xref_table = tb->tab_row; P.xref_start = tb->xref_start; P.table_rows = tb->table_rows;
-        P.bounds = tb->r_bounds;
-        P.mats = (v == VAR_ROW_EXACT) ? tb->mats_exact : tb->mats_fast;
-        P.res = tb->res; P.status = tb->status; P.iter = tb->iter; P.n_unsolved = tb->n_unsolved;
+        fill_row_params(tb, P, v == VAR_ROW_EXACT);
         e = launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, P, tb->stream);
     }
     if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -697,7 +735,7 @@ int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int dev
     // the rowlane kernel addresses its arrays with 32-bit element offsets
     const bool tile_ok = stream_dims_supported(nxc, nuc),
                row_ok = rowlane_supported(nx, nu, N) && ((long long)(batch + 3) * N * 16 < (1ll << 30));
-    if (!tile_ok && !row_ok)
+    if (!tile_ok && !row_ok && !rowdims_supported(nx, nu))
         return fail(TINY_BATCH_EUNSUPPORTED,
                     "no kernel instantiation for nx=%d nu=%d N=%d; add it to TINY_FOR_EACH_DIMS / TINY_FOR_EACH_ROWLANE", nx, nu, N);
     int ndev = 0;
@@ -707,10 +745,11 @@ int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int dev
     tb->nx = nx; tb->nu = nu; tb->N = N; tb->batch = batch; tb->device = device;
     tb->NXC = nxc; tb->NUC = nuc; tb->ntiles = (batch + TILE - 1) / TILE; tb->bpad4 = (batch + 3) / 4 * 4;
     tb->tile_dims_ok = tile_ok; tb->row_dims_ok = row_ok;
+    tb->rowmath_ok = rowdims_supported(nx, nu) && ((long long)(batch + 3) * N * 16 < (1ll << 30));
     tb->xfam_floats = (size_t)tb->ntiles * N * WAVE * nxc;
     tb->ufam_floats = (size_t)tb->ntiles * (N - 1) * WAVE * nuc;
     tb->pair_floats = (size_t)tb->bpad4 * N * 16;
-    tb->layout = row_ok ? LAYOUT_ROW : LAYOUT_TILE;
+    tb->layout = (row_ok || !tile_ok) ? LAYOUT_ROW : LAYOUT_TILE;
     auto cleanup = [&](int rc) { tiny_batch_destroy(tb); return rc; };
     if (hipSetDevice(device) != hipSuccess) return cleanup(fail(TINY_BATCH_EHIP, "hipSetDevice(%d) failed", device));
     if (int rc = alloc_layout(tb, tb->layout)) return cleanup(rc);
@@ -741,7 +780,7 @@ void tiny_batch_destroy(TinyBatch *tb)
     (void)hipFree(tb->tab_tile); (void)hipFree(tb->tab_row); (void)hipFree(tb->xref_start);
     (void)hipFree(tb->res); (void)hipFree(tb->status); (void)hipFree(tb->iter); (void)hipFree(tb->n_unsolved);
     (void)hipFree(tb->opnd); (void)hipFree(tb->qvec); (void)hipFree(tb->mats_exact); (void)hipFree(tb->mats_fast);
-    (void)hipFree(tb->dA); (void)hipFree(tb->dB); (void)hipFree(tb->x0buf); (void)hipFree(tb->staging);
+    (void)hipFree(tb->dA); (void)hipFree(tb->dB); (void)hipFree(tb->x0buf); (void)hipFree(tb->staging); (void)hipFree(tb->conv_dev);
     if (tb->ev0) (void)hipEventDestroy(tb->ev0);
     if (tb->ev1) (void)hipEventDestroy(tb->ev1);
     delete tb;
@@ -894,6 +933,19 @@ int tiny_batch_solve(TinyBatch *tb)
     int n = 0;
     TRY(tiny_batch_wait(tb, &n));
     return n > 0 ? 1 : 0;
+}
+
+int tiny_batch_forward_pass(TinyBatch *tb) { CHECK_TB(tb); return run_step(tb, STEP_FORWARD_PASS, nullptr, nullptr); }
+int tiny_batch_update_slack(TinyBatch *tb) { CHECK_TB(tb); return run_step(tb, STEP_UPDATE_SLACK, nullptr, nullptr); }
+int tiny_batch_update_dual(TinyBatch *tb) { CHECK_TB(tb); return run_step(tb, STEP_UPDATE_DUAL, nullptr, nullptr); }
+int tiny_batch_update_linear_cost(TinyBatch *tb) { CHECK_TB(tb); return run_step(tb, STEP_UPDATE_LINEAR_COST, nullptr, nullptr); }
+int tiny_batch_backward_pass_grad(TinyBatch *tb) { CHECK_TB(tb); return run_step(tb, STEP_BACKWARD_PASS_GRAD, nullptr, nullptr); }
+int tiny_batch_termination_condition(TinyBatch *tb, int *converged)
+{
+    CHECK_TB(tb);
+    int n_true = 0;
+    TRY(run_step(tb, STEP_TERMINATION_CONDITION, converged, &n_true));
+    return n_true;
 }
 
 int tiny_batch_get_x(TinyBatch *tb, float *x) { return tiny_batch_get_array(tb, TINY_ARR_X, x); }

@@ -97,10 +97,17 @@ struct RowParams
     int *status, *iter, *n_unsolved;
 };
 
+// (nx, nu) pairs with single-function kernels (admm_steps.hip), any N
+#define TINY_FOR_EACH_ROWDIMS(X) X(12, 4) X(4, 1) X(8, 3)
+enum { STEP_FORWARD_PASS = 0, STEP_UPDATE_SLACK, STEP_UPDATE_DUAL, STEP_UPDATE_LINEAR_COST, STEP_TERMINATION_CONDITION,
+       STEP_BACKWARD_PASS_GRAD };
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 bool rowlane_supported(int nx, int nu, int N);
 hipError_t launch_admm_rowlane(int nx, int nu, int N, bool exact, const RowParams &P, hipStream_t stream);
+bool rowdims_supported(int nx, int nu);
+hipError_t launch_admm_step(int nx, int nu, bool exact, int fn, const RowParams &P, int *conv_out, hipStream_t stream);
 
 hipError_t launch_admm_stream(int nxc, int nuc, const SolveParams &P, hipStream_t stream);
 

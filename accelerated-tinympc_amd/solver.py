@@ -58,6 +58,8 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch_reset_dual_variables": [P],
         "tiny_batch_solve": [P], "tiny_batch_solve_async": [P], "tiny_batch_wait": [P, I],
         "tiny_batch_get_x": [P, F], "tiny_batch_get_u": [P, F],
+        "tiny_batch_forward_pass": [P], "tiny_batch_update_slack": [P], "tiny_batch_update_dual": [P],
+        "tiny_batch_update_linear_cost": [P], "tiny_batch_backward_pass_grad": [P], "tiny_batch_termination_condition": [P, I],
         "tiny_batch_get_status": [P, I, I, F], "tiny_batch_set_status": [P, I, I, F],
         "tiny_batch_set_array": [P, C.c_int, F], "tiny_batch_get_array": [P, C.c_int, F],
         "tiny_batch_reset_workspace": [P],
@@ -205,6 +207,19 @@ class TinyBatchSolver:
         n = C.c_int(0)
         self._check(self.lib.tiny_batch_wait(self._h, C.byref(n)))
         return n.value
+
+    # -- the six step functions of admm.hpp:12-18 ----------------------------------------------------
+    def forward_pass(self): self._check(self.lib.tiny_batch_forward_pass(self._h))
+    def update_slack(self): self._check(self.lib.tiny_batch_update_slack(self._h))
+    def update_dual(self): self._check(self.lib.tiny_batch_update_dual(self._h))
+    def update_linear_cost(self): self._check(self.lib.tiny_batch_update_linear_cost(self._h))
+    def backward_pass_grad(self): self._check(self.lib.tiny_batch_backward_pass_grad(self._h))
+
+    def termination_condition(self):
+        """Returns the per-instance boolean the reference function returns (residual fields are updated on the device)."""
+        conv = np.zeros(self.B, np.int32)
+        self._check(self.lib.tiny_batch_termination_condition(self._h, conv.ctypes.data_as(C.POINTER(C.c_int))))
+        return conv.astype(bool)
 
     def get_x(self): return self.get_array("x")
     def get_u(self): return self.get_array("u")

@@ -103,6 +103,21 @@ extern "C"
      * Any pointer may be NULL. */
     int tiny_batch_get_status(TinyBatch *tb, int *iter /*[B]*/, int *status /*[B]*/, float *residuals /*[B][4]*/);
 
+    /* ---- the six step functions the reference exports next to tiny_solve (src/tinympc/admm.hpp:12-18), batched ----
+     * Each reads and writes the device-resident workspace exactly as the reference function reads and writes
+     * TinyWorkspace (forward_pass admm.cpp:27-37, update_slack :45-61, update_dual :67-71, update_linear_cost :77-85,
+     * backward_pass_grad :15-22).  tiny_solve's own bookkeeping (status, iter, v=vnew, z=znew) is NOT part of them,
+     * as in the reference.  Available for problem classes with nx + nu <= 16 (any N). */
+    int tiny_batch_forward_pass(TinyBatch *tb);
+    int tiny_batch_update_slack(TinyBatch *tb);
+    int tiny_batch_update_dual(TinyBatch *tb);
+    int tiny_batch_update_linear_cost(TinyBatch *tb);
+    int tiny_batch_backward_pass_grad(TinyBatch *tb);
+    /* termination_condition (admm.cpp:91-109): updates the residual fields when iter % check_termination == 0 and
+     * writes, per instance, 1 where the reference function would return true (converged may be NULL).
+     * Returns the number of such instances (>= 0) or a negative error. */
+    int tiny_batch_termination_condition(TinyBatch *tb, int *converged /*[B]*/);
+
     /* ---- asynchronous form ----------------------------------------------------------------- */
     int tiny_batch_solve_async(TinyBatch *tb);                 /* enqueue on the stream, do not wait */
     /* wait for the stream; *n_unsolved = number of instances whose tiny_solve returned 1 */

@@ -68,6 +68,16 @@ def _problem_struct(T):
     return OracleProblem
 
 
+def _work_struct(T):
+    P = C.POINTER(T.ct)
+
+    class OracleWork(C.Structure):
+        _fields_ = ([(n, P) for n in STATE_ORDER] + [(n, P) for n in ("u_min", "u_max", "x_min", "x_max", "Xref")] +
+                    [("primal_residual_state", T.ct), ("primal_residual_input", T.ct),
+                     ("dual_residual_state", T.ct), ("dual_residual_input", T.ct), ("status", C.c_int), ("iter", C.c_int)])
+    return OracleWork
+
+
 def _batch_struct(T):
     P = C.POINTER(T.ct)
 
@@ -158,6 +168,35 @@ class Oracle(_Solver):
                        ("Kinf", "Pinf", "Quu_inv", "AmBKt", "Adyn", "Bdyn", "Q")],
                        s["abs_pri_tol"], s["abs_dua_tol"], s["max_iter"], s["check_termination"],
                        s["en_state_bound"], s["en_input_bound"])
+
+    STEP_FUNCTIONS = ("forward_pass", "update_slack", "update_dual", "update_linear_cost", "termination_condition",
+                      "backward_pass_grad")
+
+    def step(self, fn, st, x_min, x_max, u_min, u_max, Xref):
+        """Apply ONE of the six step functions of admm.hpp:12-18 to every instance, in place on `st`.
+        Returns the per-instance return value (only termination_condition returns something: a bool array)."""
+        assert fn in self.STEP_FUNCTIONS
+        B, ins, (sx, su, sr) = self._prep(st, x_min, x_max, u_min, u_max, Xref)
+        ct, WS = self.T.ct, _work_struct(self.T)
+        f = getattr(self.lib, f"oracle_{fn}_{self.T.suf}")
+        f.argtypes, f.restype = [C.POINTER(self.PS), C.POINTER(WS)], C.c_int
+        ps = self._pstruct()
+        nxt, nut = self.nx * self.N, self.nu * (self.N - 1)
+        out = np.zeros(B, bool)
+        for b in range(B):
+            def sl(a, stride, n):
+                flat = a.reshape(-1)
+                return _ptr(flat[b * stride:b * stride + n] if stride else flat[:n], ct)
+            ptrs = [sl(st[k], nxt if k in STATE_X else nut, nxt if k in STATE_X else nut) for k in STATE_ORDER]
+            inp = [sl(ins[0], su, nut), sl(ins[1], su, nut), sl(ins[2], sx, nxt), sl(ins[3], sx, nxt), sl(ins[4], sr, nxt)]
+            r = st["residuals"][b]
+            w = WS(*ptrs, *inp, r[0], r[1], r[2], r[3], int(st["status"][b]), int(st["iter"][b]))
+            rv = f(C.byref(ps), C.byref(w))
+            if fn == "termination_condition":
+                out[b] = bool(rv)
+                st["residuals"][b] = (w.primal_residual_state, w.primal_residual_input, w.dual_residual_state,
+                                      w.dual_residual_input)
+        return out
 
     def solve(self, st, x_min, x_max, u_min, u_max, Xref, nthreads=1, ftz=False):
         """One tiny_solve() per instance, in place on `st`.  Returns #instances that hit max_iter."""

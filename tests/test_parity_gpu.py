@@ -444,3 +444,69 @@ def test_full_size_properties(tinympc, oracle_mod, variant, config, B):
     r64 = None if exact else yardstick(O, prob, s, pre, xref_of(idx), bnds)
     compare_states(got, st, prob, f"{config} B={B} sample {variant}", ref64=r64, exact=exact)
     sol.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# the six step functions of admm.hpp:12-18 as separate batched calls
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["quad30", "quad_window", "cartpole", "odd_8_3_7", "quad_N17"])
+@pytest.mark.parametrize("exact", [True, False])
+def test_step_functions_individually(tinympc, oracle_mod, case, exact):
+    """Each exported step function, applied to a random workspace, against the oracle's restatement of the same
+    reference function: bitwise in exact arithmetic, rounding-level in fast arithmetic.  Then one ADMM iteration
+    composed from the six calls in tiny_solve's order (admm.cpp:117-144)."""
+    O, pr = oracle_mod, tinympc.problems
+    prob = {"quad30": lambda: pr.quadrotor(20, 30), "quad_window": lambda: pr.quadrotor(20, 30),
+            "cartpole": lambda: pr.cartpole(10), "odd_8_3_7": lambda: pr.random_system(8, 3, 7, seed=99),
+            "quad_N17": lambda: pr.quadrotor(20, 17)}[case]()   # N=17 has no fused rowlane instantiation
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    B = 23
+    rng = np.random.default_rng(7)
+    bnds = tuple(a * s for a, s in zip(pr.bounds_arrays(prob), (0.2, 0.2, 1.0, 1.0)))  # tight enough to clip
+    st = O.new_state(B, nx, nu, N)
+    for k in STATE_ORDER:
+        st[k][:] = (rng.standard_normal(st[k].shape) * 0.3).astype(np.float32)
+    st["iter"][:] = rng.integers(1, 9, size=B)
+    st["status"][:] = 11
+    st["residuals"][:] = rng.uniform(0, 1, size=(B, 4)).astype(np.float32)
+    settings = dict(O.DEFAULT_SETTINGS, check_termination=2, abs_pri_tol=0.5, abs_dua_tol=5.0)
+    sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+    sol.select_kernel(0 if exact else (3 if (nx, nu, N) != (12, 4, 17) else 0))
+    if not exact and (nx, nu, N) == (12, 4, 17):
+        sol.close(); pytest.skip("fast arithmetic is selected through the rowlane-fast variant, which N=17 lacks")
+    sol.set_bounds(*bnds)
+    if case == "quad_window":
+        _, table, start = pr.tracking_batch(B, N, seed=2)
+        sol.set_xref_window(table, start)
+        xref = pr.expand_windows(table, start, N)
+    else:
+        xref = (rng.standard_normal((B, N, nx)) * 0.3).astype(np.float32)
+        sol.set_xref(xref)
+    orc = O.Oracle(prob, np.float32, settings)
+
+    def check(what):
+        got = sol.get_state()
+        for k in STATE_ORDER + ("residuals",):
+            if exact:
+                assert np.array_equal(got[k], st[k]), f"{case} {what}: {k} not bitwise equal"
+            else:
+                scale = max(1.0, float(np.abs(st[k]).max()))
+                assert np.max(np.abs(got[k].astype(np.float64) - st[k])) <= 2e-5 * scale, f"{case} {what}: {k}"
+
+    for fn in O.Oracle.STEP_FUNCTIONS:
+        sol.set_state(st)
+        ref_rv = orc.step(fn, st, *bnds, xref)
+        rv = getattr(sol, fn)()
+        if fn == "termination_condition":
+            assert np.array_equal(rv, ref_rv) or not exact
+        check(fn)
+    # one iteration assembled from the six calls
+    sol.set_state(st)
+    for fn in ("forward_pass", "update_slack", "update_dual", "update_linear_cost"):
+        orc.step(fn, st, *bnds, xref); getattr(sol, fn)()
+    orc.step("termination_condition", st, *bnds, xref); sol.termination_condition()
+    st["v"][:] = st["vnew"]; st["z"][:] = st["znew"]
+    sol.set_array("v", sol.get_array("vnew")); sol.set_array("z", sol.get_array("znew"))
+    orc.step("backward_pass_grad", st, *bnds, xref); sol.backward_pass_grad()
+    check("composed iteration")
+    sol.close()
