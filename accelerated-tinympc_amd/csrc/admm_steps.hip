@@ -121,6 +121,163 @@ __global__ __launch_bounds__(WAVE) void admm_step_kernel(const RowParams P, cons
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// admm_rowstream_kernel — the fused solve (tiny_solve, admm.cpp:111-152) in the row mapping for ANY horizon N: same
+// arithmetic and same per-instance early exit as admm_rowlane_kernel, but the loop-carried state lives in the workspace
+// arrays (streamed through L2/HBM every iteration) instead of registers, so nothing is unrolled over N.  It is the
+// fallback for (nx, nu) classes whose N has no register-resident instantiation, and keeps exact mode bit-identical
+// to the reference there too.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NX, int NU, bool EXACT>
+__global__ __launch_bounds__(WAVE) void admm_rowstream_kernel(const RowParams P)
+{
+    const int lane = threadIdx.x, r16 = lane & 15;
+    const int inst = blockIdx.x * 4 + (lane >> 4);
+    const bool valid = inst < P.batch;
+    const bool is_x = r16 < NX, is_u = (r16 >= NX) && (r16 < NX + NU);
+    const int N = P.N;
+    const int rowbase = (inst * N) * 16 + r16;
+    const float rho = P.rho;
+    const float2 *bnd = reinterpret_cast<const float2 *>(P.bounds);
+    RowGains<NX, NU> G;
+    G.load(P.mats, r16);
+    const float qrow = P.mats[(2 * NX + 2 * NU) * 16 + r16];
+    int wstart = 0;
+    if (P.xref_mode == 1 && valid) wstart = P.xref_start[inst];
+    const int xref_off = inst * (int)P.xref_inst_stride + r16;
+    auto xref_at = [&](int i) {
+        if (P.xref_mode == 1)
+        {
+            int row = wstart + i;
+            row = row < P.table_rows ? row : P.table_rows - 1;
+            return P.xref_table[row * 16 + r16];
+        }
+        return P.xref[xref_off + i * 16];
+    };
+    const float x0 = P.xu[rowbase];
+    const float pterm = terminal_term<NX, NU, EXACT>(P.mats, r16, xref_at(N - 1));
+    int st = TINY_STATUS_UNSOLVED_, itn = 1;
+    float r_ps = 0.f, r_pi = 0.f, r_ds = 0.f, r_di = 0.f;
+    if (valid)
+    {
+        r_ps = P.res[4 * inst + 0]; r_pi = P.res[4 * inst + 1];
+        r_ds = P.res[4 * inst + 2]; r_di = P.res[4 * inst + 3];
+    }
+    bool active = valid && (P.max_iter > 0);
+    for (int it = 0; it < P.max_iter; ++it)
+    {
+        if (!__any(active)) break;
+        const bool last_iter = (it == P.max_iter - 1);
+        const bool zero_state = (it == 0) && (P.cold_start != 0);
+        const bool zero_duals = (it == 0) && ((P.cold_start | P.duals_zero) != 0);
+        if (active)
+        {
+            float s = x0, pri = 0.f, dua = 0.f, t1 = 0.f;
+            for (int i = 0; i < N; i++)
+            {
+                const int o = rowbase + i * 16;
+                float sv, xn = 0.f;
+                if (i < N - 1) lqr_step<NX, NU, EXACT>(G, is_x, is_u, s, zero_state ? 0.f : P.pd[o], sv, xn);
+                else sv = is_x ? s : 0.f;
+                const float2 lh = bnd[i * 16 + r16];
+                const float a = zero_duals ? 0.f : P.gy[o];
+                const float bprev = zero_state ? 0.f : P.vz[o];
+                const float t = __builtin_amdgcn_fmed3f(sv + a, lh.x, lh.y);
+                const float an = (a + sv) - t;
+                pri = fmaxf(pri, fabsf(sv - t));
+                dua = fmaxf(dua, fabsf(bprev - t));
+                P.vzn[o] = t;
+                P.gy[o] = an;
+                if (last_iter) P.xu[o] = sv;
+                t1 = t - an;
+                s = xn;
+            }
+            const float pN = lin_cost<EXACT>(pterm, rho, t1);
+            P.pd[rowbase + (N - 1) * 16] = is_x ? pN : 0.f;
+            const float pri_x = row_max(is_x ? pri : 0.f), dua_x = row_max(is_x ? dua : 0.f);
+            const float pri_u = row_max(is_u ? pri : 0.f), dua_u = row_max(is_u ? dua : 0.f);
+            itn = it + 1;
+            bool conv = false;
+            if ((it + 1) % P.check_termination == 0)
+            {
+                r_ps = pri_x; r_ds = dua_x * rho; r_pi = pri_u; r_di = dua_u * rho;
+                conv = (r_ps < P.abs_pri_tol) && (r_pi < P.abs_pri_tol) && (r_ds < P.abs_dua_tol) && (r_di < P.abs_dua_tol);
+            }
+            if (conv)
+            {
+                st = TINY_STATUS_SOLVED_;
+                active = false;
+            }
+            else
+            {
+                float p = pN;
+                P.vz[rowbase + (N - 1) * 16] = P.vzn[rowbase + (N - 1) * 16];
+                for (int i = N - 2; i >= 0; i--)
+                {
+                    const int o = rowbase + i * 16;
+                    const float sni = P.vzn[o];
+                    const float cq = is_x ? -(xref_at(i) * qrow) : 0.f;
+                    float pn, dd;
+                    riccati_step<NX, NU, EXACT>(G, is_x, p, lin_cost<EXACT>(cq, rho, sni - P.gy[o]), pn, dd);
+                    P.pd[o] = is_u ? dd : pn;
+                    P.vz[o] = sni;
+                    p = pn;
+                }
+            }
+        }
+    }
+    if (P.max_iter <= 0)
+    {
+        if (valid && r16 == 0)
+        {
+            P.status[inst] = TINY_STATUS_UNSOLVED_;
+            P.iter[inst] = 1;
+            atomicAdd(P.n_unsolved, 1);
+        }
+        return;
+    }
+    {
+        // live-out: q, r (admm.cpp:80-82) and, for converged instances, x,u regenerated from the frozen d
+        const bool solved = (st == TINY_STATUS_SOLVED_);
+        float s = x0;
+        for (int i = 0; i < N; i++)
+        {
+            const int o = rowbase + i * 16;
+            float sv, xn = 0.f;
+            if (i < N - 1) lqr_step<NX, NU, EXACT>(G, is_x, is_u, s, P.pd[o], sv, xn);
+            else sv = is_x ? s : 0.f;
+            if (valid && solved) P.xu[o] = sv;
+            s = xn;
+            const float cq = is_x ? -(xref_at(i) * qrow) : 0.f;
+            const float lin = lin_cost<EXACT>(cq, rho, P.vzn[o] - P.gy[o]);
+            if (valid) P.qr[o] = (i < N - 1 || is_x) ? lin : 0.f;
+        }
+        if (valid && r16 == 0)
+        {
+            P.res[4 * inst + 0] = r_ps; P.res[4 * inst + 1] = r_pi;
+            P.res[4 * inst + 2] = r_ds; P.res[4 * inst + 3] = r_di;
+            P.status[inst] = st;
+            P.iter[inst] = itn;
+            if (!solved) atomicAdd(P.n_unsolved, 1);
+        }
+    }
+}
+
+hipError_t launch_admm_rowstream(int nx, int nu, bool exact, const RowParams &P, hipStream_t stream)
+{
+    const int nblocks = (P.batch + 3) / 4;
+#define TINY_ROWSTREAM_DISPATCH(NX, NU)                                                                                \
+    if (nx == NX && nu == NU)                                                                                          \
+    {                                                                                                                  \
+        if (exact) hipLaunchKernelGGL((admm_rowstream_kernel<NX, NU, true>), dim3(nblocks), dim3(WAVE), 0, stream, P);  \
+        else hipLaunchKernelGGL((admm_rowstream_kernel<NX, NU, false>), dim3(nblocks), dim3(WAVE), 0, stream, P);      \
+        return hipGetLastError();                                                                                      \
+    }
+    TINY_FOR_EACH_ROWDIMS(TINY_ROWSTREAM_DISPATCH)
+    return hipErrorInvalidValue;
+}
+
 bool rowdims_supported(int nx, int nu)
 {
 #define TINY_ROWDIMS_CHECK(NX, NU) \

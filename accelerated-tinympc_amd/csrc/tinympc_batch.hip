@@ -564,13 +564,14 @@ int prepare_inputs(TinyBatch *tb, int layout)
 int resolve_variant(TinyBatch *tb, int *out)
 {
     int v = tb->variant;
-    const bool row_ok = tb->row_dims_ok && bounds_all_shared(tb);
+    // row variants: register-resident kernel when (nx,nu,N) is instantiated, else the any-N row kernel with the state in HBM
+    const bool row_ok = (tb->row_dims_ok || tb->rowmath_ok) && bounds_all_shared(tb);
     if (v == VAR_AUTO) v = row_ok ? VAR_ROW_EXACT : VAR_STREAM;
     if ((v == VAR_ROW_EXACT || v == VAR_ROW_FAST) && !row_ok)
     {
-        if (tb->row_dims_ok)
-            return fail(TINY_BATCH_EUNSUPPORTED, "the rowlane kernel needs batch-shared bounds; per-instance bounds run on the streaming kernel");
-        return fail(TINY_BATCH_EUNSUPPORTED, "no rowlane kernel instantiation for nx=%d nu=%d N=%d", tb->nx, tb->nu, tb->N);
+        if (tb->row_dims_ok || tb->rowmath_ok)
+            return fail(TINY_BATCH_EUNSUPPORTED, "the row kernels need batch-shared bounds; per-instance bounds run on the streaming kernel");
+        return fail(TINY_BATCH_EUNSUPPORTED, "no row kernel instantiation for nx=%d nu=%d (needs nx + nu <= 16)", tb->nx, tb->nu);
     }
     if (v == VAR_STREAM && !tb->tile_dims_ok)
         return fail(TINY_BATCH_EUNSUPPORTED, "no streaming kernel instantiation for nx=%d nu=%d", tb->nx, tb->nu);
@@ -585,7 +586,8 @@ void update_kname(TinyBatch *tb)
     const std::string keep = g_err;
     if (resolve_variant(tb, &v)) { tb->kname = "unsupported"; g_err = keep; return; }
     if (v == VAR_STREAM) snprintf(nm, sizeof nm, "stream<%d,%d>", tb->NXC, tb->NUC);
-    else snprintf(nm, sizeof nm, "rowlane<%d,%d,%d,%s>", tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT ? "exact" : "fast");
+    else if (tb->row_dims_ok) snprintf(nm, sizeof nm, "rowlane<%d,%d,%d,%s>", tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT ? "exact" : "fast");
+    else snprintf(nm, sizeof nm, "rowstream<%d,%d,%s>", tb->nx, tb->nu, v == VAR_ROW_EXACT ? "exact" : "fast");
     tb->kname = nm;
 }
 
@@ -689,7 +691,8 @@ int launch_solve(TinyBatch *tb)
     {
         RowParams P;
         fill_row_params(tb, P, v == VAR_ROW_EXACT);
-        e = launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, P, tb->stream);
+        e = tb->row_dims_ok ? launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, P, tb->stream)
+                            : launch_admm_rowstream(tb->nx, tb->nu, v == VAR_ROW_EXACT, P, tb->stream);
     }
     if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
     if (tb->timing)

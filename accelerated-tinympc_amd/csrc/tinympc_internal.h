@@ -107,6 +107,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 bool rowlane_supported(int nx, int nu, int N);
 hipError_t launch_admm_rowlane(int nx, int nu, int N, bool exact, const RowParams &P, hipStream_t stream);
 bool rowdims_supported(int nx, int nu);
+hipError_t launch_admm_rowstream(int nx, int nu, bool exact, const RowParams &P, hipStream_t stream);
 hipError_t launch_admm_step(int nx, int nu, bool exact, int fn, const RowParams &P, int *conv_out, hipStream_t stream);
 
 hipError_t launch_admm_stream(int nxc, int nuc, const SolveParams &P, hipStream_t stream);

@@ -510,3 +510,39 @@ def test_step_functions_individually(tinympc, oracle_mod, case, exact):
     orc.step("backward_pass_grad", st, *bnds, xref); sol.backward_pass_grad()
     check("composed iteration")
     sol.close()
+
+
+@pytest.mark.parametrize("case", [("quad", 5), ("quad", 17), ("quad", 45), ("cartpole", 25), ("odd", 12)])
+@pytest.mark.parametrize("variant_name", ["row_exact", "row_fast"])
+def test_any_horizon_row_kernel(tinympc, oracle_mod, case, variant_name):
+    """Horizons without a register-resident instantiation run on the any-N row kernel (state in HBM): still bitwise
+    in exact arithmetic.  Cold start, then a warm start with reset duals; early exit."""
+    O, pr = oracle_mod, tinympc.problems
+    exact = VARIANTS[variant_name][1]
+    kind, N = case
+    prob = {"quad": lambda: pr.quadrotor(20, N), "cartpole": lambda: pr.cartpole(N),
+            "odd": lambda: pr.random_system(8, 3, N, seed=99)}[kind]()
+    nx, nu = prob["nx"], prob["nu"]
+    B = 70
+    rng = np.random.default_rng(N)
+    x0 = (rng.uniform(-0.3, 0.3, size=(B, nx))).astype(np.float32)
+    xref = (rng.standard_normal((B, N, nx)) * 0.1).astype(np.float32)
+    bnds = pr.bounds_arrays(prob)
+    settings = dict(O.DEFAULT_SETTINGS, max_iter=60)
+    sol = make_solver(tinympc, prob, B, settings, xref, variant_name, bnds)
+    assert sol.kernel_name().startswith("rowstream"), sol.kernel_name()
+    orc = O.Oracle(prob, np.float32, settings)
+    st = O.new_state(B, nx, nu, N)
+    st["x"][:, 0] = x0
+    sol.set_x0(x0)
+    for k in range(2):
+        st["y"][:] = 0; st["g"][:] = 0
+        sol.reset_dual_variables()
+        pre = O.copy_state(st)
+        orc.solve(st, *bnds, xref, nthreads=8)
+        sol.solve()
+        r64 = None if exact else yardstick(O, prob, settings, pre, xref, bnds)
+        compare_states(sol.get_state(), st, prob, f"{case} k={k} {variant_name}", ref64=r64, exact=exact)
+        if not exact:
+            sol.set_state(st)
+    sol.close()
