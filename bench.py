@@ -111,12 +111,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # rehearsal knobs (one-GPU box): TINYMPC_BENCH_DEVICE pins every rank to one device, TINYMPC_BENCH_BACKEND=gloo
+    # replaces RCCL (two ranks cannot share a GPU under RCCL).  The driver's real runs use neither.
+    dev_index = int(os.environ.get("TINYMPC_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("TINYMPC_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pr = T.problems
     prob = pr.quadrotor(20, N)
@@ -128,7 +135,7 @@ def main():
     settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1, en_state_bound=1, en_input_bound=1)
     if args.mode == "fixed10":
         settings.update(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=10)
-    sol = T.TinyBatchSolver(prob, B, device=local_rank, settings=settings)
+    sol = T.TinyBatchSolver(prob, B, device=dev_index, settings=settings)
     if args.kernel:
         sol.select_kernel(args.kernel)
     sol.set_bounds(*pr.bounds_arrays(prob))
@@ -165,7 +172,7 @@ def main():
         kernel_ms.append(sol.last_solve_ms())
     n_unsolved = sol.wait()
     iters, status, _ = sol.get_status()
-    agg = T.sharding.reduce_stats(dist, "cuda", iters, status, flops_of(iters, status), dt)
+    agg = T.sharding.reduce_stats(dist, "cuda" if backend == "nccl" else "cpu", iters, status, flops_of(iters, status), dt)
     dt = agg["wall_s"]  # max over ranks
     total_solves = B * world * args.steps
     value = total_solves / dt
