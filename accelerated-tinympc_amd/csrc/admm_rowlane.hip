@@ -103,7 +103,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
 
     int st = TINY_STATUS_UNSOLVED_, itn = 1; // admm.cpp:114-115
     float r_ps = 0.f, r_pi = 0.f, r_ds = 0.f, r_di = 0.f;
-    if (valid)
+    if (valid && !P.cold_start) // reset_workspace() zeroes the residual fields too
     {
         r_ps = P.res[4 * inst + 0]; r_pi = P.res[4 * inst + 1];
         r_ds = P.res[4 * inst + 2]; r_di = P.res[4 * inst + 3];

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(WAVE) void admm_stream_kernel(const SolveParams P)
     // per-instance scalars (work->status, work->iter and the four residual fields are live across solves)
     int st = 0, itn = 0;
     float r_ps = 0.f, r_pi = 0.f, r_ds = 0.f, r_di = 0.f;
-    if (valid)
+    if (valid && !P.cold_start) // reset_workspace() zeroes the residual fields too
     {
         r_ps = P.res[4 * inst + 0]; r_pi = P.res[4 * inst + 1];
         r_ds = P.res[4 * inst + 2]; r_di = P.res[4 * inst + 3];

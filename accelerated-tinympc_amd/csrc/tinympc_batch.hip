@@ -300,6 +300,9 @@ int flush_pending(TinyBatch *tb)
             if (id == TINY_ARR_X) TRY(launch_zero(tb, work_ptr(tb, id), tb->layout, 0, 1, tb->N - 1));
             else TRY(launch_zero(tb, work_ptr(tb, id), tb->layout, fam, 0, steps));
         }
+        HIP_TRY(hipMemsetAsync(tb->res, 0, (size_t)tb->batch * 4 * sizeof(float), tb->stream));
+        HIP_TRY(hipMemsetAsync(tb->status, 0, (size_t)tb->batch * sizeof(int), tb->stream));
+        HIP_TRY(hipMemsetAsync(tb->iter, 0, (size_t)tb->batch * sizeof(int), tb->stream));
         tb->cold_pending = false;
         tb->duals_zero_pending = false;
     }
@@ -958,6 +961,7 @@ int tiny_batch_get_status(TinyBatch *tb, int *iter, int *status, float *residual
 {
     CHECK_TB(tb);
     TRY(set_device(tb));
+    TRY(flush_pending(tb));
     if (iter) HIP_TRY(hipMemcpyAsync(iter, tb->iter, (size_t)tb->batch * sizeof(int), hipMemcpyDeviceToHost, tb->stream));
     if (status) HIP_TRY(hipMemcpyAsync(status, tb->status, (size_t)tb->batch * sizeof(int), hipMemcpyDeviceToHost, tb->stream));
     if (residuals) HIP_TRY(hipMemcpyAsync(residuals, tb->res, (size_t)tb->batch * 4 * sizeof(float), hipMemcpyDeviceToHost, tb->stream));
@@ -969,6 +973,7 @@ int tiny_batch_set_status(TinyBatch *tb, const int *iter, const int *status, con
 {
     CHECK_TB(tb);
     TRY(set_device(tb));
+    TRY(flush_pending(tb));
     if (iter) HIP_TRY(hipMemcpyAsync(tb->iter, iter, (size_t)tb->batch * sizeof(int), hipMemcpyHostToDevice, tb->stream));
     if (status) HIP_TRY(hipMemcpyAsync(tb->status, status, (size_t)tb->batch * sizeof(int), hipMemcpyHostToDevice, tb->stream));
     if (residuals) HIP_TRY(hipMemcpyAsync(tb->res, residuals, (size_t)tb->batch * 4 * sizeof(float), hipMemcpyHostToDevice, tb->stream));
@@ -1005,9 +1010,6 @@ int tiny_batch_reset_workspace(TinyBatch *tb)
     // reads d,v,z,y,g (and p) as zero in its first iteration and overwrites the rest, any other reader triggers the
     // zero fill (flush_pending).
     TRY(launch_zero(tb, work_ptr(tb, TINY_ARR_X), tb->layout, 0, 0, 1));
-    HIP_TRY(hipMemsetAsync(tb->res, 0, (size_t)tb->batch * 4 * sizeof(float), tb->stream));
-    HIP_TRY(hipMemsetAsync(tb->status, 0, (size_t)tb->batch * sizeof(int), tb->stream));
-    HIP_TRY(hipMemsetAsync(tb->iter, 0, (size_t)tb->batch * sizeof(int), tb->stream));
     HIP_TRY(hipMemsetAsync(tb->x0buf, 0, (size_t)tb->batch * tb->nx * sizeof(float), tb->stream));
     tb->cold_pending = true;
     tb->duals_zero_pending = false;

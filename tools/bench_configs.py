@@ -1,0 +1,66 @@
+"""Developer aid: kernel-time throughput of every BASELINE.json configuration on one GPU (not the headline bench)."""
+import sys, time
+from pathlib import Path
+import numpy as np
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import accelerated_tinympc_amd as T
+
+pr = T.problems
+
+
+def measure(name, prob, B, setup, variants=(0,), settings=None, reps=5):
+    for v in variants:
+        sol = T.TinyBatchSolver(prob, B, settings=settings)
+        try:
+            sol.select_kernel(v)
+        except T.TinyBatchError as e:
+            print(f"{name:34s} variant {v}: unsupported ({e})"); sol.close(); continue
+        sol.set_bounds(*pr.bounds_arrays(prob))
+        x0 = setup(sol)
+        sol.enable_timing(True)
+        ms = []
+        for r in range(reps + 1):
+            sol.reset_workspace(); sol.set_x0(x0); sol.solve_async(); sol.synchronize()
+            if r: ms.append(sol.last_solve_ms())
+        it, st, _ = sol.get_status()
+        print(f"{name:34s} {sol.kernel_name():28s} B={B:6d}  {np.mean(ms):8.3f} ms  {B / np.mean(ms) * 1e3:12.4g} solves/s  "
+              f"mean iters {it.mean():6.2f}  converged {np.mean(st == 1):.3f}")
+        sol.close()
+
+
+def hover(B, N=30):
+    x0, xref = pr.hover_batch(B, N)
+    def f(sol): sol.set_xref(xref); return x0
+    return f
+
+
+def track(B, N=30):
+    x0, table, start = pr.tracking_batch(B, N)
+    def f(sol): sol.set_xref_window(table, start); return x0
+    return f
+
+
+def rand(B, prob):
+    rng = np.random.default_rng(0)
+    x0 = rng.uniform(-1, 1, size=(B, prob["nx"])).astype(np.float32)
+    def f(sol): sol.set_xref(np.zeros((prob["N"], prob["nx"]), np.float32)); return x0
+    return f
+
+
+q30 = pr.quadrotor(20, 30)
+measure("cfg1 hover 1 instance", q30, 1, hover(1), (0, 3, 1))
+measure("cfg2 hover 4096", q30, 4096, hover(4096), (0, 3, 1))
+measure("cfg3 tracking 65536", q30, 65536, track(65536), (0, 3, 1))
+r32 = pr.random_system(32, 16, 50)
+measure("cfg4 random 32/16/50 2048 (1 of 8 GPUs)", r32, 2048, rand(2048, r32), (0,))
+measure("cfg4 random 32/16/50 16384", r32, 16384, rand(16384, r32), (0,))
+cp = pr.cartpole(10)
+rngc = np.random.default_rng(1)
+def cps(sol):
+    sol.set_xref(np.zeros((10, 4), np.float32)); return np.tile(np.array([[0, 0, 0.1, 0]], np.float32), (sol.B, 1)) + rngc.uniform(-0.05, 0.05, size=(sol.B, 4)).astype(np.float32)
+measure("cfg5 cartpole 32768", cp, 32768, cps, (0, 3, 1), settings=dict(max_iter=150))
+measure("cfg5 quadrotor hover 32768", q30, 32768, hover(32768), (0, 3))
+q17 = pr.quadrotor(20, 17)
+measure("any-N quadrotor N=17 65536", q17, 65536, track(65536, 17), (0, 3, 1))
+fixed = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=10)
+measure("cfg3 tracking fixed 10 iters", q30, 65536, track(65536), (0, 3, 1), settings=fixed)
