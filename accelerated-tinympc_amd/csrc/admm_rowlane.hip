@@ -144,7 +144,6 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
                 s = xn;
                 lh = lh_next;
                 b_pref = b_next;
-                __builtin_amdgcn_sched_barrier(0); // keep the steps apart (VGPR pressure)
             }
             {
                 const float t1 = sn[(N - 1) * WAVE] - a[N - 1];
@@ -185,7 +184,6 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
                     b[i * WAVE] = sni;                     // admm.cpp:141-142
                     P.pd[rowbase + i * 16] = is_u ? dd : pn; // [p_i ; d_i] of this sweep
                     p = pn;
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
