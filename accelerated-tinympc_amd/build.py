@@ -16,7 +16,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libtinympc_hip.so"
 SOURCES = ["tinympc_batch.hip", "admm_stream.hip", "admm_rowlane.hip", "admm_steps.hip", "riccati.cpp"]
-HEADERS = [CSRC / "tinympc_internal.h", CSRC / "rowlane_math.h", CSRC / "dpp_ops_gen.h", PKG.parent / "include" / "tinympc_batch.h"]
+HEADERS = [CSRC / "tinympc_internal.h", CSRC / "rowlane_math.h", CSRC / "tile_math.h", CSRC / "dpp_ops_gen.h", PKG.parent / "include" / "tinympc_batch.h"]
 # -ffp-contract=off : exact arithmetic must not fuse a*b+c; the fast paths call fma explicitly
 # -fno-slp-vectorize: hipcc otherwise pairs scalar fp32 adds into v_pk_add_f32 (+ v_mov to build the pairs), which on
 #                     gfx950 is slower than two plain v_add_f32 (measured, tools/micro/*.hip)
