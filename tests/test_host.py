@@ -86,3 +86,19 @@ def test_batch_generators_are_deterministic(tinympc):
     assert w.shape == (100, 30, 12) and np.array_equal(w[5, 3], t[s[5] + 3])
     x0, xr = pr.hover_batch(10, 30)
     assert x0.shape == (10, 12) and xr.shape == (30, 12) and xr[0, 2] == 2.0
+
+
+def test_cpp_example_compiles_and_links_against_the_c_abi(tinympc, tmp_path):
+    """examples/quadrotor_tracking_batched.cpp uses nothing but include/tinympc_batch.h: plain g++ must build it."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    tinympc.build.build()
+    lib_dir = ROOT / "accelerated-tinympc_amd" / "lib"
+    out = tmp_path / "example"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", f"-I{ROOT / 'include'}",
+                        str(ROOT / "examples" / "quadrotor_tracking_batched.cpp"), f"-L{lib_dir}", "-ltinympc_hip",
+                        f"-Wl,-rpath,{lib_dir}", "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (ROOT / "accelerated-tinympc_amd" / "data" / "quadrotor_20hz.bin").stat().st_size == 557 * 8

@@ -546,3 +546,30 @@ def test_any_horizon_row_kernel(tinympc, oracle_mod, case, variant_name):
         if not exact:
             sol.set_state(st)
     sol.close()
+
+
+def test_mixed_problem_classes_on_two_streams(tinympc, oracle_mod):
+    """BASELINE.json config 5's mixed-size batch: a cartpole class and a quadrotor class are two handles; enqueued on
+    two HIP streams they run concurrently and each stays bitwise equal to the oracle."""
+    import torch
+    O, pr = oracle_mod, tinympc.problems
+    cases = []
+    for prob, B in ((pr.cartpole(10), 3000), (pr.quadrotor(20, 30), 2000)):
+        nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+        rng = np.random.default_rng(B)
+        x0 = rng.uniform(-0.2, 0.2, size=(B, nx)).astype(np.float32)
+        xref = np.zeros((N, nx), np.float32)
+        bnds = pr.bounds_arrays(prob)
+        stream = torch.cuda.Stream()
+        sol = tinympc.TinyBatchSolver(prob, B, settings=dict(max_iter=150))
+        sol.set_stream(stream.cuda_stream)
+        sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
+        st = O.new_state(B, nx, nu, N); st["x"][:, 0] = x0
+        O.Oracle(prob, np.float32, dict(O.DEFAULT_SETTINGS, max_iter=150)).solve(st, *bnds, xref, nthreads=8)
+        cases.append((sol, st, stream))
+    for sol, _, _ in cases:
+        sol.solve_async()          # both launches are in flight before either is waited for
+    for sol, st, _ in cases:
+        sol.wait()
+        assert_bitwise(sol.get_state(), st, sol.kernel_name())
+        sol.close()
