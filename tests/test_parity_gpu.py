@@ -551,7 +551,8 @@ def test_any_horizon_row_kernel(tinympc, oracle_mod, case, variant_name):
 def test_mixed_problem_classes_on_two_streams(tinympc, oracle_mod):
     """BASELINE.json config 5's mixed-size batch: a cartpole class and a quadrotor class are two handles; enqueued on
     two HIP streams they run concurrently and each stays bitwise equal to the oracle."""
-    import torch
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")  # the runtime the library itself links (already loaded)
     O, pr = oracle_mod, tinympc.problems
     cases = []
     for prob, B in ((pr.cartpole(10), 3000), (pr.quadrotor(20, 30), 2000)):
@@ -560,9 +561,10 @@ def test_mixed_problem_classes_on_two_streams(tinympc, oracle_mod):
         x0 = rng.uniform(-0.2, 0.2, size=(B, nx)).astype(np.float32)
         xref = np.zeros((N, nx), np.float32)
         bnds = pr.bounds_arrays(prob)
-        stream = torch.cuda.Stream()
         sol = tinympc.TinyBatchSolver(prob, B, settings=dict(max_iter=150))
-        sol.set_stream(stream.cuda_stream)
+        stream = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(stream)) == 0
+        sol.set_stream(stream.value)
         sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
         st = O.new_state(B, nx, nu, N); st["x"][:, 0] = x0
         O.Oracle(prob, np.float32, dict(O.DEFAULT_SETTINGS, max_iter=150)).solve(st, *bnds, xref, nthreads=8)
@@ -573,3 +575,5 @@ def test_mixed_problem_classes_on_two_streams(tinympc, oracle_mod):
         sol.wait()
         assert_bitwise(sol.get_state(), st, sol.kernel_name())
         sol.close()
+    for _, _, stream in cases:
+        hip.hipStreamDestroy(stream)
