@@ -1,38 +1,34 @@
-// admm_rowlane.hip — register-resident batched TinyMPC ADMM kernel for small problems (nx + nu <= 16).
+// admm_rowlane.hip — state-on-chip batched TinyMPC ADMM kernel for small problems (nx + nu <= 16).
 //
-// Restates tiny_solve() (src/tinympc/admm.cpp:111-152) with the WHOLE loop-carried state of an
-// instance (d, y, g, v, z, plus vnew/znew and p) held in VGPRs for the entire solve: HBM is touched
-// only to read the live-in arrays once and to write the live-out arrays once.
+// Restates tiny_solve() (src/tinympc/admm.cpp:111-152) with the WHOLE loop-carried state of an instance kept on chip for
+// the entire solve (two VGPRs and two LDS words per horizon step and lane, see below): HBM is touched only to read the
+// live-in arrays once and to write the live-out arrays once.
 //
-// Mapping ("row lanes"): a DPP row = 16 lanes = ONE instance, 4 instances per wavefront.  Lane r of
-// the row owns row r of the stacked vector [x ; u]: r < NX -> x(r), NX <= r < NX+NU -> u(r-NX)
-// (quadrotor: 12 + 4 = exactly 16).  A gain x state product y = M s is NX (or NU) instructions
-//      t_k = M[r][k] * s[k]      with s[k] fetched by the DPP modifier row_newbcast:k
-// i.e. the cross-lane broadcast is free (an operand modifier of v_mul_f32 / v_fmac_f32), the gain
-// row sits in the lane's own VGPRs, and the x rows (A, AmBKt) and the u rows (Kinf, Bdyn^T) of a
-// sweep step execute in the same instructions.  Everything is unrolled over the horizon so that the
-// state arrays index registers statically.
+// Mapping ("row lanes"): a DPP row = 16 lanes = ONE instance, 4 instances per wavefront, one wavefront per workgroup.
+// Lane r of the row owns row r of the stacked vector [x ; u]: r < NX -> x(r), NX <= r < NX+NU -> u(r-NX) (quadrotor:
+// 12 + 4 = exactly 16).  A gain x state product y = M s is NX (or NU) instructions
+//      t_k = M[r][k] * s[k]      with s[k] fetched by the DPP operand modifier row_newbcast:k,
+// the gain row sits in the lane's own VGPRs, and the x rows (A, AmBKt) and the u rows (Kinf, Bdyn^T) of a sweep step
+// execute in the same instructions.  (On gfx950 a DPP instruction issues in 4 cycles against 2 for a plain fp32
+// mul/add/fma — tools/micro/*.hip — so the broadcast costs one issue slot, not zero.)  The horizon is fully unrolled
+// so that the per-step state indexes registers statically.
 //
-// Two arithmetic modes (template parameter EXACT):
-//   EXACT = true : every product and every sum is a separately rounded fp32 operation, summed in the
-//                  order the reference's SSE2 Eigen build uses (seq / halving tree / packet tree, see RowPlans below;
-//                  Eigen/src/Core/Redux.h, ProductEvaluators.h, GeneralProduct.h of the vendored Eigen 3.4.90).
-//                  Results are BITWISE identical to the compiled reference, iteration counts included.
-//   EXACT = false: one v_fmac_f32_dpp per multiply-add (k-ascending fma chain), ~2x fewer instructions.
+// Two arithmetic modes (template parameter EXACT), shared with the other row kernels through rowlane_math.h:
+//   EXACT = true : every product and every sum is a separately rounded fp32 operation, summed in the order the
+//                  reference's SSE2 Eigen build uses (RowPlans).  Results are BITWISE identical to the compiled
+//                  reference, iteration counts included.
+//   EXACT = false: one v_fmac_f32_dpp per multiply-add (k-ascending fma chain), about half the instructions.
+//
+// Converged instances are frozen by running the iteration body under `if (active)`: the 16 lanes of an instance leave
+// EXEC together, so row broadcasts and row reductions of the remaining instances only ever read active lanes.
 #include "rowlane_math.h"
 
 namespace tinympc
 {
 
-// DPP row-broadcast multiply / multiply-accumulate chains: dpp_products, dpp_fma_dot, dpp_fma_acc.
-// hipcc does not fold v_mov_b32_dpp into v_fmac_f32 and separates consecutive asm statements by an s_nop,
-// so every chain is ONE generated inline-asm statement (tools/gen_dpp_ops.py).  A VALU write of `src`
-// followed by a DPP read of it needs two wait states which the compiler does not track inside asm: every
-// chain starts with s_nop 1.
 template <int NX, int NU, int N, bool EXACT>
 __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P)
 {
-    using PL = RowPlans<NX, NU>;
     const int lane = threadIdx.x;
     const int r16 = lane & 15;
     const int inst = blockIdx.x * 4 + (lane >> 4);
@@ -57,7 +53,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
     RowGains<NX, NU> G;
     G.load(P.mats, r16);
 
-    // ---- per-instance state, all in registers --------------------------------------------------------
+    // ---- per-instance state ------------------------------------------------------------------------------
     //   a[i]  : g_i (x rows) | y_i (u rows)           duals                                (VGPR)
     //   c[i]  : -(Xref_i.*Q) | d_i                    reference cost term | feed-forward   (VGPR)
     //   b[i]  : v_i          | z_i                    previous slack                       (LDS)

@@ -8,6 +8,11 @@
 namespace tinympc
 {
 
+// DPP row-broadcast chains (dpp_products, dpp_fma_dot, dpp_fma_acc) come from dpp_ops_gen.h: hipcc neither folds
+// v_mov_b32_dpp into v_fmac_f32 nor keeps consecutive asm statements adjacent, so every chain is ONE generated inline-asm
+// statement (tools/gen_dpp_ops.py).  A VALU write of the broadcast source followed by a DPP read needs two wait states
+// the compiler does not track inside asm: every chain starts with s_nop 1.
+
 // ---------------------------------------------------------------------------------------------
 // Reduction orders of the reference build.  Eigen 3.4.90 picks them at compile time from storage order, sizes and
 // the SSE2 packet size (4 floats):
