@@ -577,3 +577,40 @@ def test_mixed_problem_classes_on_two_streams(tinympc, oracle_mod):
         sol.close()
     for _, _, stream in cases:
         hip.hipStreamDestroy(stream)
+
+
+def test_reference_wrapper_names_drive_the_hovering_loop():
+    """An FFI script written for the reference's generated wrapper library (set_x0 / reset_dual_variables /
+    call_tiny_solve / get_u, tiny_wrapper.hpp:14-23) runs unchanged against libtinympc_wrapper.so: the 70-step hovering
+    loop of examples/quadrotor_hovering.cpp reproduces the compiled reference's controls and iteration counts bit for bit."""
+    import ctypes as C
+    from pathlib import Path
+    meta, prob, solves, z = load_fixture("quad_hover_f32_N30")
+    lib = C.CDLL(str(Path(__file__).resolve().parents[1] / "accelerated-tinympc_amd" / "lib" / "libtinympc_wrapper.so"))
+    F = C.POINTER(C.c_float)
+    cm = lambda m: np.ascontiguousarray(np.asarray(m, np.float32).T).ravel()
+    fp = lambda a: a.ctypes.data_as(F)
+    mats = [cm(prob[k]) for k in ("Kinf", "Pinf", "Quu_inv", "AmBKt", "Adyn", "Bdyn")] + [np.asarray(prob["Q"], np.float32)]
+    lib.tiny_wrapper_setup.argtypes = [C.c_int] * 3 + [C.c_float] + [F] * 7 + [C.c_float] * 2 + [C.c_int] * 5
+    assert lib.tiny_wrapper_setup(12, 4, 30, prob["rho"], *[fp(m) for m in mats], 1e-3, 1e-3, 100, 1, 1, 1, 0) == 0
+    for fn in ("set_x0", "set_xref", "set_umin", "set_umax", "set_xmin", "set_xmax", "get_x", "get_u"):
+        getattr(lib, fn).argtypes, getattr(lib, fn).restype = [F, C.c_int], None
+    xmn, xmx, umn, umx = bounds_of(prob, np.float32)
+    lib.set_xmin(fp(xmn), 0); lib.set_xmax(fp(xmx), 0); lib.set_umin(fp(umn), 0); lib.set_umax(fp(umx), 0)
+    xref = np.ascontiguousarray(solves[0]["xref"], np.float32)
+    lib.set_xref(fp(xref), 0)
+    A, Bm = prob["Adyn"].astype(np.float32), prob["Bdyn"].astype(np.float32)
+    x0 = solves[0]["pre"]["x"][0, 0].copy()
+    u = np.zeros((29, 4), np.float32)
+    it, stt = C.c_int(), C.c_int()
+    iters, u0s = [], []
+    for k in range(70):
+        lib.set_x0(fp(x0), 0)
+        lib.reset_dual_variables(0)
+        lib.call_tiny_solve(0)
+        lib.get_u(fp(u), 0)
+        assert lib.tiny_wrapper_last_status(C.byref(it), C.byref(stt)) == 0
+        iters.append(it.value); u0s.append(u[0].copy())
+        x0 = (x0 @ A.T + u[0] @ Bm.T).astype(np.float32)
+    assert np.array_equal(np.array(iters), z["trace_iter"]) and np.array_equal(np.array(u0s), z["trace_u0"])
+    lib.tiny_wrapper_teardown()
