@@ -17,7 +17,7 @@ CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libtinympc_hip.so"
 WRAPPER_LIB = PKG / "lib" / "libtinympc_wrapper.so"  # same-name twin of the reference's generated wrapper library
 SOURCES = ["tinympc_batch.hip", "admm_stream.hip", "admm_rowlane.hip", "admm_steps.hip", "riccati.cpp"]
-WRAPPER_SRC = CSRC / "wrapper_compat.cpp"
+WRAPPER_SRCS = [CSRC / "wrapper_compat.cpp", CSRC / "admm_compat.cpp"]
 HEADERS = [CSRC / "tinympc_internal.h", CSRC / "rowlane_math.h", CSRC / "tile_math.h", CSRC / "dpp_ops_gen.h", PKG.parent / "include" / "tinympc_batch.h"]
 # -ffp-contract=off : exact arithmetic must not fuse a*b+c; the fast paths call fma explicitly
 # -fno-slp-vectorize: hipcc otherwise pairs scalar fp32 adds into v_pk_add_f32 (+ v_mov to build the pairs), which on
@@ -33,7 +33,8 @@ def needs_build() -> bool:
     if not LIB.exists() or not WRAPPER_LIB.exists():
         return True
     t = min(LIB.stat().st_mtime, WRAPPER_LIB.stat().st_mtime)
-    deps = [s for s, _ in _objs()] + HEADERS + [Path(__file__), WRAPPER_SRC, PKG.parent / "include" / "tinympc_wrapper.h"]
+    inc = PKG.parent / "include"
+    deps = [s for s, _ in _objs()] + HEADERS + [Path(__file__), *WRAPPER_SRCS, inc / "tinympc_wrapper.h", inc / "tinympc_admm.h", inc / "tinympc_batch.h"]
     return any(d.stat().st_mtime > t for d in deps if d.exists())
 
 
@@ -59,7 +60,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
     # libtinympc_wrapper.so: plain host C++ on top of the C-ABI, finds libtinympc_hip.so next to itself
-    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", str(WRAPPER_LIB), str(WRAPPER_SRC), f"-L{LIB.parent}",
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", str(WRAPPER_LIB), *[str(w) for w in WRAPPER_SRCS], f"-L{LIB.parent}",
            "-ltinympc_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))

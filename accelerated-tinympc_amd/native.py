@@ -1,0 +1,109 @@
+"""ctypes binding of the reference's native API names (include/tinympc_admm.h): TinyCache / TinySettings /
+TinyWorkspace / TinySolver with plain float arrays, `tiny_solve` and the step functions of src/tinympc/admm.hpp:10-18,
+exported by lib/libtinympc_wrapper.so for ONE instance.
+
+`NativeSolver` owns the numpy arrays the structs point to (members are column-major like the reference's Eigen
+matrices, i.e. the numpy arrays here are [N][nx] / [N-1][nu], C order) and is what the parity tests drive.  All compute
+happens in the HIP library; nothing here has a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from . import build as _build
+
+WRAPPER_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libtinympc_wrapper.so"
+F = C.POINTER(C.c_float)
+
+STATE_MEMBERS = ("x", "u", "q", "r", "p", "d", "v", "vnew", "z", "znew", "g", "y")
+X_FAMILY = ("x", "q", "p", "v", "vnew", "g", "x_min", "x_max", "Xref")
+
+
+class TinyCache(C.Structure):  # types.hpp:26-34
+    _fields_ = [("rho", C.c_float), ("Kinf", F), ("Pinf", F), ("Quu_inv", F), ("AmBKt", F), ("coeff_d2p", F)]
+
+
+class TinySettings(C.Structure):  # types.hpp:39-47
+    _fields_ = [("abs_pri_tol", C.c_float), ("abs_dua_tol", C.c_float), ("max_iter", C.c_int),
+                ("check_termination", C.c_int), ("en_state_bound", C.c_int), ("en_input_bound", C.c_int)]
+
+
+class TinyWorkspace(C.Structure):  # types.hpp:52-97
+    _fields_ = ([("nx", C.c_int), ("nu", C.c_int), ("N", C.c_int)] + [(m, F) for m in STATE_MEMBERS] +
+                [("primal_residual_state", C.c_float), ("primal_residual_input", C.c_float),
+                 ("dual_residual_state", C.c_float), ("dual_residual_input", C.c_float), ("status", C.c_int), ("iter", C.c_int),
+                 ("Q", F), ("R", F), ("Adyn", F), ("Bdyn", F),
+                 ("u_min", F), ("u_max", F), ("x_min", F), ("x_max", F), ("Xref", F), ("Uref", F), ("Qu", F)])
+
+
+class TinySolver(C.Structure):  # types.hpp:102-107
+    _fields_ = [("settings", C.POINTER(TinySettings)), ("cache", C.POINTER(TinyCache)), ("work", C.POINTER(TinyWorkspace))]
+
+
+_lib = None
+
+
+def load_wrapper_library(build_if_missing: bool = False) -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not WRAPPER_LIB_PATH.exists():
+            if not build_if_missing:
+                raise RuntimeError(f"{WRAPPER_LIB_PATH} is missing: run `python accelerated-tinympc_amd/build.py`")
+            _build.build()
+        lib = C.CDLL(str(WRAPPER_LIB_PATH))
+        S = C.POINTER(TinySolver)
+        lib.tiny_solve.argtypes, lib.tiny_solve.restype = [S], C.c_int
+        for fn in ("forward_pass", "update_slack", "update_dual", "update_linear_cost", "backward_pass_grad", "update_primal"):
+            getattr(lib, fn).argtypes, getattr(lib, fn).restype = [S], None
+        lib.termination_condition.argtypes, lib.termination_condition.restype = [S], C.c_bool
+        lib.tiny_admm_set_device.argtypes = [C.c_int]
+        _lib = lib
+    return _lib
+
+
+class NativeSolver:
+    """A TinySolver with numpy-backed members: `ns.a["x"]` etc. are the arrays, `ns.work` the TinyWorkspace struct."""
+
+    def __init__(self, prob: dict, settings: dict, device: int = 0):
+        self.lib = load_wrapper_library()
+        self.lib.tiny_admm_set_device(device)
+        nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+        self.nx, self.nu, self.N = nx, nu, N
+        cm = lambda m: np.ascontiguousarray(np.asarray(m, np.float32).T).ravel()  # column-major flat
+        self.m = {k: cm(prob[k]) for k in ("Kinf", "Pinf", "Quu_inv", "AmBKt", "Adyn", "Bdyn")}
+        self.m["Q"] = np.ascontiguousarray(prob["Q"], np.float32)
+        self.a = {k: np.zeros((N, nx) if k in X_FAMILY else (N - 1, nu), np.float32)
+                  for k in STATE_MEMBERS + ("u_min", "u_max", "x_min", "x_max", "Xref")}
+        p = lambda arr: arr.ctypes.data_as(F)
+        self.cache = TinyCache(float(prob["rho"]), p(self.m["Kinf"]), p(self.m["Pinf"]), p(self.m["Quu_inv"]), p(self.m["AmBKt"]), None)
+        self.settings = TinySettings(settings["abs_pri_tol"], settings["abs_dua_tol"], settings["max_iter"],
+                                     settings["check_termination"], settings["en_state_bound"], settings["en_input_bound"])
+        self.work = TinyWorkspace()
+        self.work.nx, self.work.nu, self.work.N = nx, nu, N
+        for k, arr in self.a.items():
+            setattr(self.work, k, p(arr))
+        self.work.Q, self.work.Adyn, self.work.Bdyn = p(self.m["Q"]), p(self.m["Adyn"]), p(self.m["Bdyn"])
+        self.solver = TinySolver(C.pointer(self.settings), C.pointer(self.cache), C.pointer(self.work))
+
+    def _check(self):
+        code = self.lib.tiny_admm_last_error_code()
+        if code < 0:
+            raise RuntimeError(f"libtinympc_wrapper.so reported error {code}")
+
+    def tiny_solve(self) -> int:
+        rc = self.lib.tiny_solve(C.byref(self.solver))
+        self._check()
+        return rc
+
+    def call(self, fn: str):
+        rv = getattr(self.lib, fn)(C.byref(self.solver))
+        self._check()
+        return rv
+
+    @property
+    def residuals(self):
+        w = self.work
+        return np.array([w.primal_residual_state, w.primal_residual_input, w.dual_residual_state, w.dual_residual_input], np.float32)

@@ -1,6 +1,7 @@
 """CPU tests of the host side: C-ABI surface, Riccati host routine, problem data."""
 import ctypes as C
 import re
+import subprocess
 from pathlib import Path
 
 import numpy as np
@@ -102,6 +103,11 @@ def test_cpp_example_compiles_and_links_against_the_c_abi(tinympc, tmp_path):
                         f"-Wl,-rpath,{lib_dir}", "-o", str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert (ROOT / "accelerated-tinympc_amd" / "data" / "quadrotor_20hz.bin").stat().st_size == 557 * 8
+    # the hovering example over the reference's own names (include/tinympc_admm.h) links against the wrapper library
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", f"-I{ROOT / 'include'}",
+                        str(ROOT / "examples" / "quadrotor_hovering_native.cpp"), f"-L{lib_dir}", "-ltinympc_wrapper",
+                        f"-Wl,-rpath,{lib_dir}", "-o", str(tmp_path / "hover_native")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
 
 
 WRAPPER_SYMBOLS = ["set_x0", "set_xref", "set_umin", "set_umax", "set_xmin", "set_xmax", "reset_dual_variables",
@@ -120,3 +126,38 @@ def test_wrapper_library_exports_the_reference_wrapper_names(tinympc):
     # before setup every call is a reported no-op, never a crash
     lib.reset_dual_variables(0)
     assert lib.tiny_wrapper_last_status(None, None) < 0
+
+
+NATIVE_SYMBOLS = ["tiny_solve", "update_primal", "backward_pass_grad", "forward_pass", "update_slack", "update_dual",
+                  "update_linear_cost", "termination_condition"]  # src/tinympc/admm.hpp:10-18
+
+
+def test_native_names_header_is_plain_c_and_matches_the_binding(tinympc, tmp_path):
+    """include/tinympc_admm.h compiles as C, declares the functions of the reference's admm.hpp under the same names,
+    the library exports them, and the ctypes structs of native.py have the compiled layout."""
+    from accelerated_tinympc_amd import native
+    tinympc.build.build()
+    lib = C.CDLL(str(ROOT / "accelerated-tinympc_amd" / "lib" / "libtinympc_wrapper.so"))
+    for s in NATIVE_SYMBOLS:
+        assert hasattr(lib, s), s
+    hdr = Path("/root/reference/src/tinympc/admm.hpp")
+    if hdr.exists():
+        names = re.findall(r"^\s*(?:int|void|bool)\s+(\w+)\s*\(TinySolver", hdr.read_text(), re.M)
+        assert sorted(names) == sorted(NATIVE_SYMBOLS)
+    members = ["nx", "x", "y", "primal_residual_state", "iter", "Q", "Bdyn", "u_min", "Xref", "Qu"]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tinympc_admm.h"\nint main(void){\n'
+                   'printf("%zu %zu %zu %zu\\n", sizeof(TinyCache), sizeof(TinySettings), sizeof(TinyWorkspace), sizeof(TinySolver));\n' +
+                   "".join(f'printf("%zu\\n", offsetof(TinyWorkspace, {m}));\n' for m in members) + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert [int(v) for v in out[:4]] == [C.sizeof(native.TinyCache), C.sizeof(native.TinySettings),
+                                         C.sizeof(native.TinyWorkspace), C.sizeof(native.TinySolver)]
+    assert [int(v) for v in out[4:]] == [getattr(native.TinyWorkspace, m).offset for m in members]
+    # member names and order are the reference's (types.hpp:52-97), with nx,nu,N in front and pointers for matrices
+    ref_types = Path("/root/reference/src/tinympc/types.hpp")
+    if ref_types.exists():
+        body = ref_types.read_text().split("Problem variables")[1].split("} TinyWorkspace")[0]
+        ref_members = re.findall(r"^\s*(?:tiny_\w+|tinytype|int)\s+(\w+);", body, re.M)
+        assert [f[0] for f in native.TinyWorkspace._fields_[3:]] == ref_members

@@ -614,3 +614,87 @@ def test_reference_wrapper_names_drive_the_hovering_loop():
         x0 = (x0 @ A.T + u[0] @ Bm.T).astype(np.float32)
     assert np.array_equal(np.array(iters), z["trace_iter"]) and np.array_equal(np.array(u0s), z["trace_u0"])
     lib.tiny_wrapper_teardown()
+
+
+def test_native_names_tiny_solve_hovering_loop(tinympc):
+    """examples/quadrotor_hovering.cpp:90-114 written against include/tinympc_admm.h (TinySolver{settings,cache,work},
+    tiny_solve): the caller owns the workspace arrays, warm start travels through them like in the reference.  Controls,
+    iteration counts and the full workspace of the recorded solves equal the compiled reference's bit for bit."""
+    from accelerated_tinympc_amd import native
+    meta, prob, solves, z = load_fixture("quad_hover_f32_N30")
+    ns = native.NativeSolver(prob, solves[0]["settings"])
+    for k, arr in zip(("x_min", "x_max", "u_min", "u_max"), bounds_of(prob, np.float32)):
+        ns.a[k][:] = arr
+    ns.a["Xref"][:] = solves[0]["xref"]
+    A, Bm = prob["Adyn"].astype(np.float32), prob["Bdyn"].astype(np.float32)
+    x0 = solves[0]["pre"]["x"][0, 0].copy()
+    recorded = {s["k"]: s for s in solves}
+    iters, u0s = [], []
+    for k in range(70):
+        ns.a["x"][0] = x0                       # hovering.cpp:95
+        ns.a["y"][:] = 0; ns.a["g"][:] = 0      # :100-101
+        rc = ns.tiny_solve()                    # :104
+        iters.append(ns.work.iter); u0s.append(ns.a["u"][0].copy())
+        if k in recorded:
+            post = recorded[k]["post"]
+            assert rc == recorded[k]["rc"]
+            for name in STATE_ORDER:
+                assert np.array_equal(ns.a[name], post[name][0]), f"step {k}: {name}"
+            assert np.array_equal(ns.residuals, post["residuals"][0]) and ns.work.status == post["status"][0]
+        x0 = (x0 @ A.T + ns.a["u"][0] @ Bm.T).astype(np.float32)  # :110-111
+    assert np.array_equal(np.array(iters), z["trace_iter"]) and np.array_equal(np.array(u0s), z["trace_u0"])
+
+
+@pytest.mark.parametrize("case", ["quad30", "cartpole"])
+def test_native_names_step_functions(tinympc, oracle_mod, case):
+    """forward_pass ... termination_condition under the reference's own names over a caller-owned TinySolver: each call
+    leaves the structs exactly as the oracle's restatement of the same reference function does."""
+    from accelerated_tinympc_amd import native
+    O, pr = oracle_mod, tinympc.problems
+    prob = pr.quadrotor(20, 30) if case == "quad30" else pr.cartpole(10)
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    rng = np.random.default_rng(11)
+    bnds = tuple(a * s for a, s in zip(pr.bounds_arrays(prob), (0.2, 0.2, 1.0, 1.0)))
+    settings = dict(O.DEFAULT_SETTINGS, check_termination=2, abs_pri_tol=0.5, abs_dua_tol=5.0)
+    st = O.new_state(1, nx, nu, N)
+    for k in STATE_ORDER:
+        st[k][:] = (rng.standard_normal(st[k].shape) * 0.3).astype(np.float32)
+    st["iter"][:] = 4; st["status"][:] = 11
+    st["residuals"][:] = rng.uniform(0, 1, size=(1, 4)).astype(np.float32)
+    xref = (rng.standard_normal((1, N, nx)) * 0.3).astype(np.float32)
+    orc = O.Oracle(prob, np.float32, settings)
+    ns = native.NativeSolver(prob, settings)
+    for k, arr in zip(("x_min", "x_max", "u_min", "u_max"), bnds):
+        ns.a[k][:] = arr
+    ns.a["Xref"][:] = xref[0]
+
+    def load(state):
+        for k in STATE_ORDER:
+            ns.a[k][:] = state[k][0]
+        w = ns.work
+        (w.primal_residual_state, w.primal_residual_input, w.dual_residual_state, w.dual_residual_input) = map(float, state["residuals"][0])
+        w.iter, w.status = int(state["iter"][0]), int(state["status"][0])
+
+    for fn in O.Oracle.STEP_FUNCTIONS:
+        load(st)
+        ref_rv = orc.step(fn, st, *bnds, xref)
+        rv = ns.call(fn)
+        if fn == "termination_condition":
+            assert bool(rv) == bool(ref_rv[0])
+        for k in STATE_ORDER:
+            assert np.array_equal(ns.a[k], st[k][0]), f"{fn}: {k}"
+        assert np.array_equal(ns.residuals, st["residuals"][0]), fn
+        assert ns.work.iter == st["iter"][0] and ns.work.status == st["status"][0], fn
+    # tiny_solve from the same random warm state, with max_iter small enough to exhaust and large enough to converge
+    for max_iter in (3, 200):
+        settings2 = dict(settings, max_iter=max_iter, check_termination=1, abs_pri_tol=1e-3, abs_dua_tol=1e-3)
+        ns.settings.max_iter, ns.settings.check_termination = max_iter, 1
+        ns.settings.abs_pri_tol = ns.settings.abs_dua_tol = 1e-3
+        st2 = O.copy_state(st)
+        load(st2)
+        rcs = O.Oracle(prob, np.float32, settings2).solve(st2, *bnds, xref)
+        rc = ns.tiny_solve()
+        assert rc == (1 if st2["status"][0] == 11 else 0)
+        for k in STATE_ORDER:
+            assert np.array_equal(ns.a[k], st2[k][0]), f"tiny_solve max_iter={max_iter}: {k}"
+        assert ns.work.iter == st2["iter"][0] and ns.work.status == st2["status"][0]
