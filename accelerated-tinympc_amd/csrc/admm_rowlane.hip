@@ -26,7 +26,7 @@
 namespace tinympc
 {
 
-template <int NX, int NU, int N, bool EXACT>
+template <int NX, int NU, int N, bool EXACT, bool H16>
 __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P)
 {
     const int lane = threadIdx.x;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
     // each is written once and read once per iteration, so they do not need a VGPR per horizon step.
     __shared__ float sn_lds[N * WAVE];
     __shared__ float b_lds[N * WAVE];
-    for (int e = lane; e < N * 16; e += WAVE) bnd[e] = reinterpret_cast<const float2 *>(P.bounds)[e];
+    for (int e = lane; e < N * 16; e += WAVE) bnd[e] = ld_bounds<H16>(P.bounds, e);
     __syncthreads();
     float *sn = sn_lds + lane;   // sn[i * WAVE]
     float *b = b_lds + lane;     // b[i * WAVE]
@@ -80,22 +80,22 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             {
                 int row = wstart + i;
                 row = row < P.table_rows ? row : P.table_rows - 1;
-                xr = P.xref_table[row * 16 + r16];
+                xr = ldw<H16>(P.xref_table, row * 16 + r16);
             }
             else
-                xr = P.xref[xref_off + i * 16];
-            const float pd = cold ? 0.f : P.pd[rowbase + i * 16];
-            c[i] = is_x ? -(xr * qrow) : pd;       // admm.cpp:81  q(i,j) = -(Xref(i,j) * Q(i))
-            b[i * WAVE] = cold ? 0.f : P.vz[rowbase + i * 16];
-            a[i] = zdual ? 0.f : P.gy[rowbase + i * 16];
+                xr = ldw<H16>(P.xref, xref_off + i * 16);
+            const float pd = cold ? 0.f : ldw<H16>(P.pd, rowbase + i * 16);
+            c[i] = is_x ? rnd<H16>(-(xr * qrow)) : pd;       // admm.cpp:81  q(i,j) = -(Xref(i,j) * Q(i))
+            b[i * WAVE] = cold ? 0.f : ldw<H16>(P.vz, rowbase + i * 16);
+            a[i] = zdual ? 0.f : ldw<H16>(P.gy, rowbase + i * 16);
             sn[i * WAVE] = 0.f;
             if (i == N - 1) xrN = xr;
         }
     }
-    const float x0 = P.xu[rowbase]; // x.col(0) on x rows (u rows hold stale u_0, never used as x)
+    const float x0 = ldw<H16>(P.xu, rowbase); // x.col(0) on x rows (u rows hold stale u_0, never used as x)
 
     // -(Xref_{N-1}^T Pinf): constant during a solve (admm.cpp:83)
-    const float pterm = terminal_term<NX, NU, EXACT>(P.mats, r16, xrN);
+    const float pterm = terminal_term<NX, NU, EXACT, H16>(P.mats, r16, xrN);
 
     int st = TINY_STATUS_UNSOLVED_, itn = 1; // admm.cpp:114-115
     float r_ps = 0.f, r_pi = 0.f, r_ds = 0.f, r_di = 0.f;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
     float pN = 0.f; // p_{N-1} of the last executed forward sweep (x rows)
     bool ran_bwd = false;
 
-    auto lqr = [&](float s_, float ci, float &sv, float &xn) { lqr_step<NX, NU, EXACT>(G, is_x, is_u, s_, ci, sv, xn); };
+    auto lqr = [&](float s_, float ci, float &sv, float &xn) { lqr_step<NX, NU, EXACT, H16>(G, is_x, is_u, s_, ci, sv, xn); };
 
     bool active = valid && (P.max_iter > 0);
     for (int it = 0; it < P.max_iter; ++it)
@@ -128,22 +128,22 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
                 float sv, xn = 0.f;
                 if (i < N - 1) lqr(s, c[i], sv, xn);
                 else sv = is_x ? s : 0.f;
-                float t = sv + a[i];                       // admm.cpp:47-48
+                float t = rnd<H16>(sv + a[i]);             // admm.cpp:47-48
                 // admm.cpp:51-60: min(hi, max(lo, t)).  The host stores lo := min(lo, hi), which makes the median
                 // identical to that expression for every t (and +-inf where a bound is disabled).
                 t = __builtin_amdgcn_fmed3f(t, lh.x, lh.y);
-                a[i] = (a[i] + sv) - t;                    // admm.cpp:69-70
+                a[i] = rnd<H16>((a[i] + sv) - t);          // admm.cpp:69-70
                 pri = fmaxf(pri, fabsf(sv - t));           // admm.cpp:95,97
                 dua = fmaxf(dua, fabsf(b_pref - t));       // admm.cpp:96,98
                 sn[i * WAVE] = t;
-                if (last_iter) P.xu[rowbase + i * 16] = sv; // x,u of an instance that exhausts max_iter
+                if (last_iter) stw<H16>(P.xu, rowbase + i * 16, sv); // x,u of an instance that exhausts max_iter
                 s = xn;
                 lh = lh_next;
                 b_pref = b_next;
             }
             {
                 const float t1 = sn[(N - 1) * WAVE] - a[N - 1];
-                pN = lin_cost<EXACT>(pterm, rho, t1); // admm.cpp:83-84
+                pN = lin_cost<EXACT, H16>(pterm, rho, t1); // admm.cpp:83-84
             }
             // ---------------- termination_condition (admm.cpp:91-109) ----------------
             const float pri_x = row_max(is_x ? pri : 0.f), dua_x = row_max(is_x ? dua : 0.f);
@@ -175,10 +175,10 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
                     const float t1 = sni - a[i];
                     const float cq = c[i] * maskx;         // x rows: -(Xref.*Q) ; u rows: 0 (x*1 and d*0 are exact)
                     float pn, dd;
-                    riccati_step<NX, NU, EXACT>(G, is_x, p, lin_cost<EXACT>(cq, rho, t1), pn, dd); // admm.cpp:19-20,80-82
+                    riccati_step<NX, NU, EXACT, H16>(G, is_x, p, lin_cost<EXACT, H16>(cq, rho, t1), pn, dd); // admm.cpp:19-20,80-82
                     c[i] = is_u ? dd : c[i];
                     b[i * WAVE] = sni;                     // admm.cpp:141-142
-                    P.pd[rowbase + i * 16] = is_u ? dd : pn; // [p_i ; d_i] of this sweep
+                    stw<H16>(P.pd, rowbase + i * 16, is_u ? dd : pn); // [p_i ; d_i] of this sweep
                     p = pn;
                 }
             }
@@ -209,21 +209,21 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             float sv, xn = 0.f;
             if (i < N - 1) lqr(s, c[i], sv, xn);
             else sv = is_x ? s : 0.f;
-            if (solved) P.xu[o] = sv;
+            if (solved) stw<H16>(P.xu, o, sv);
             s = xn;
             const float sni = sn[i * WAVE];
             const float t1 = sni - a[i];
             const float cq = c[i] * maskx;
-            const float lin = lin_cost<EXACT>(cq, rho, t1);
-            P.qr[o] = (i < N - 1 || is_x) ? lin : 0.f;
+            const float lin = lin_cost<EXACT, H16>(cq, rho, t1);
+            stw<H16>(P.qr, o, (i < N - 1 || is_x) ? lin : 0.f);
             // p.col(N-1) is rewritten by every forward sweep (admm.cpp:83-84); the other columns and d were stored by the
             // last backward sweep this instance executed.  An instance that never ran one keeps its live-in p,d
             // (all zero after reset_workspace, which only marked them so).
-            if (i == N - 1) P.pd[o] = is_x ? pN : 0.f;
-            else if (cold && !ran_bwd) P.pd[o] = 0.f;
-            P.vz[o] = b[i * WAVE];
-            P.vzn[o] = sni;
-            P.gy[o] = a[i];
+            if (i == N - 1) stw<H16>(P.pd, o, is_x ? pN : 0.f);
+            else if (cold && !ran_bwd) stw<H16>(P.pd, o, 0.f);
+            stw<H16>(P.vz, o, b[i * WAVE]);
+            stw<H16>(P.vzn, o, sni);
+            stw<H16>(P.gy, o, a[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (r16 == 0)
@@ -245,14 +245,18 @@ bool rowlane_supported(int nx, int nu, int N)
     return false;
 }
 
-hipError_t launch_admm_rowlane(int nx, int nu, int N, bool exact, const RowParams &P, hipStream_t stream)
+hipError_t launch_admm_rowlane(int nx, int nu, int N, bool exact, bool h16, const RowParams &P, hipStream_t stream)
 {
     const int nblocks = (P.batch + 3) / 4;
+#define TINY_ROWLANE_LAUNCH(NX, NU, NN, EX, H) \
+    hipLaunchKernelGGL((admm_rowlane_kernel<NX, NU, NN, EX, H>), dim3(nblocks), dim3(WAVE), 0, stream, P)
 #define TINY_ROWLANE_DISPATCH(NX, NU, NN)                                                                   \
     if (nx == NX && nu == NU && N == NN)                                                                    \
     {                                                                                                       \
-        if (exact) hipLaunchKernelGGL((admm_rowlane_kernel<NX, NU, NN, true>), dim3(nblocks), dim3(WAVE), 0, stream, P);  \
-        else hipLaunchKernelGGL((admm_rowlane_kernel<NX, NU, NN, false>), dim3(nblocks), dim3(WAVE), 0, stream, P); \
+        if (exact && !h16) TINY_ROWLANE_LAUNCH(NX, NU, NN, true, false);                                    \
+        else if (exact) TINY_ROWLANE_LAUNCH(NX, NU, NN, true, true);                                        \
+        else if (!h16) TINY_ROWLANE_LAUNCH(NX, NU, NN, false, false);                                       \
+        else TINY_ROWLANE_LAUNCH(NX, NU, NN, false, true);                                                  \
         return hipGetLastError();                                                                           \
     }
     TINY_FOR_EACH_ROWLANE(TINY_ROWLANE_DISPATCH)

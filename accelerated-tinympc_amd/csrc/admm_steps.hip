@@ -10,7 +10,7 @@
 namespace tinympc
 {
 
-template <int NX, int NU, bool EXACT>
+template <int NX, int NU, bool EXACT, bool H16>
 __global__ __launch_bounds__(WAVE) void admm_step_kernel(const RowParams P, const int fn, int *__restrict__ conv_out)
 {
     const int lane = threadIdx.x, r16 = lane & 15;
@@ -25,32 +25,31 @@ __global__ __launch_bounds__(WAVE) void admm_step_kernel(const RowParams P, cons
     {
         RowGains<NX, NU> G;
         G.load(P.mats, r16);
-        float s = P.xu[rowbase];
+        float s = ldw<H16>(P.xu, rowbase);
         for (int i = 0; i < N - 1; i++)
         {
             float sv, xn;
-            lqr_step<NX, NU, EXACT>(G, is_x, is_u, s, P.pd[rowbase + i * 16], sv, xn);
-            if (valid) P.xu[rowbase + i * 16] = sv;
+            lqr_step<NX, NU, EXACT, H16>(G, is_x, is_u, s, ldw<H16>(P.pd, rowbase + i * 16), sv, xn);
+            if (valid) stw<H16>(P.xu, rowbase + i * 16, sv);
             s = xn;
         }
-        if (valid) P.xu[rowbase + (N - 1) * 16] = is_x ? s : 0.f;
+        if (valid) stw<H16>(P.xu, rowbase + (N - 1) * 16, is_x ? s : 0.f);
     }
     else if (fn == STEP_UPDATE_SLACK) // admm.cpp:45-61  znew = clip(u + y), vnew = clip(x + g)
     {
-        const float2 *bnd = reinterpret_cast<const float2 *>(P.bounds);
         for (int i = 0; i < N; i++)
         {
-            const float2 lh = bnd[i * 16 + r16];
-            const float t = P.xu[rowbase + i * 16] + P.gy[rowbase + i * 16];
-            if (valid) P.vzn[rowbase + i * 16] = __builtin_amdgcn_fmed3f(t, lh.x, lh.y);
+            const float2 lh = ld_bounds<H16>(P.bounds, i * 16 + r16);
+            const float t = ldw<H16>(P.xu, rowbase + i * 16) + ldw<H16>(P.gy, rowbase + i * 16);
+            if (valid) stw<H16>(P.vzn, rowbase + i * 16, __builtin_amdgcn_fmed3f(t, lh.x, lh.y));
         }
     }
     else if (fn == STEP_UPDATE_DUAL) // admm.cpp:67-71  y += u - znew, g += x - vnew
     {
         for (int i = 0; i < N; i++)
         {
-            const float a = P.gy[rowbase + i * 16];
-            if (valid) P.gy[rowbase + i * 16] = (a + P.xu[rowbase + i * 16]) - P.vzn[rowbase + i * 16];
+            const float a = ldw<H16>(P.gy, rowbase + i * 16);
+            if (valid) stw<H16>(P.gy, rowbase + i * 16, (a + ldw<H16>(P.xu, rowbase + i * 16)) - ldw<H16>(P.vzn, rowbase + i * 16));
         }
     }
     else if (fn == STEP_UPDATE_LINEAR_COST) // admm.cpp:77-85  r, q, p.col(N-1)
@@ -66,17 +65,17 @@ __global__ __launch_bounds__(WAVE) void admm_step_kernel(const RowParams P, cons
             {
                 int row = wstart + i;
                 row = row < P.table_rows ? row : P.table_rows - 1;
-                xr = P.xref_table[row * 16 + r16];
+                xr = ldw<H16>(P.xref_table, row * 16 + r16);
             }
             else
-                xr = P.xref[xref_off + i * 16];
-            const float cq = is_x ? -(xr * qrow) : 0.f;
-            t1 = P.vzn[rowbase + i * 16] - P.gy[rowbase + i * 16];
-            const float lin = lin_cost<EXACT>(cq, rho, t1);
-            if (valid) P.qr[rowbase + i * 16] = (i < N - 1 || is_x) ? lin : 0.f;
+                xr = ldw<H16>(P.xref, xref_off + i * 16);
+            const float cq = is_x ? rnd<H16>(-(xr * qrow)) : 0.f;
+            t1 = ldw<H16>(P.vzn, rowbase + i * 16) - ldw<H16>(P.gy, rowbase + i * 16);
+            const float lin = lin_cost<EXACT, H16>(cq, rho, t1);
+            if (valid) stw<H16>(P.qr, rowbase + i * 16, (i < N - 1 || is_x) ? lin : 0.f);
         }
-        const float pterm = terminal_term<NX, NU, EXACT>(P.mats, r16, xr); // xr, t1 are those of step N-1 here
-        if (valid && is_x) P.pd[rowbase + (N - 1) * 16] = lin_cost<EXACT>(pterm, rho, t1);
+        const float pterm = terminal_term<NX, NU, EXACT, H16>(P.mats, r16, xr); // xr, t1 are those of step N-1 here
+        if (valid && is_x) stw<H16>(P.pd, rowbase + (N - 1) * 16, lin_cost<EXACT, H16>(pterm, rho, t1));
     }
     else if (fn == STEP_TERMINATION_CONDITION) // admm.cpp:91-109  residual fields + the boolean it returns
     {
@@ -87,9 +86,9 @@ __global__ __launch_bounds__(WAVE) void admm_step_kernel(const RowParams P, cons
             float pri = 0.f, dua = 0.f;
             for (int i = 0; i < N; i++)
             {
-                const float sv = P.xu[rowbase + i * 16], t = P.vzn[rowbase + i * 16];
+                const float sv = ldw<H16>(P.xu, rowbase + i * 16), t = ldw<H16>(P.vzn, rowbase + i * 16);
                 pri = fmaxf(pri, fabsf(sv - t));
-                dua = fmaxf(dua, fabsf(P.vz[rowbase + i * 16] - t));
+                dua = fmaxf(dua, fabsf(ldw<H16>(P.vz, rowbase + i * 16) - t));
             }
             const float r_ps = row_max(is_x ? pri : 0.f), r_ds = row_max(is_x ? dua : 0.f) * rho;
             const float r_pi = row_max(is_u ? pri : 0.f), r_di = row_max(is_u ? dua : 0.f) * rho;
@@ -110,12 +109,12 @@ __global__ __launch_bounds__(WAVE) void admm_step_kernel(const RowParams P, cons
     {
         RowGains<NX, NU> G;
         G.load(P.mats, r16);
-        float p = P.pd[rowbase + (N - 1) * 16];
+        float p = ldw<H16>(P.pd, rowbase + (N - 1) * 16);
         for (int i = N - 2; i >= 0; i--)
         {
             float pn, dd;
-            riccati_step<NX, NU, EXACT>(G, is_x, p, P.qr[rowbase + i * 16], pn, dd);
-            if (valid) P.pd[rowbase + i * 16] = is_u ? dd : pn;
+            riccati_step<NX, NU, EXACT, H16>(G, is_x, p, ldw<H16>(P.qr, rowbase + i * 16), pn, dd);
+            if (valid) stw<H16>(P.pd, rowbase + i * 16, is_u ? dd : pn);
             p = pn;
         }
     }
@@ -129,7 +128,7 @@ __global__ __launch_bounds__(WAVE) void admm_step_kernel(const RowParams P, cons
 // fallback for (nx, nu) classes whose N has no register-resident instantiation, and keeps exact mode bit-identical
 // to the reference there too.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NX, int NU, bool EXACT>
+template <int NX, int NU, bool EXACT, bool H16>
 __global__ __launch_bounds__(WAVE) void admm_rowstream_kernel(const RowParams P)
 {
     const int lane = threadIdx.x, r16 = lane & 15;
@@ -139,7 +138,6 @@ __global__ __launch_bounds__(WAVE) void admm_rowstream_kernel(const RowParams P)
     const int N = P.N;
     const int rowbase = (inst * N) * 16 + r16;
     const float rho = P.rho;
-    const float2 *bnd = reinterpret_cast<const float2 *>(P.bounds);
     RowGains<NX, NU> G;
     G.load(P.mats, r16);
     const float qrow = P.mats[(2 * NX + 2 * NU) * 16 + r16];
@@ -151,12 +149,12 @@ __global__ __launch_bounds__(WAVE) void admm_rowstream_kernel(const RowParams P)
         {
             int row = wstart + i;
             row = row < P.table_rows ? row : P.table_rows - 1;
-            return P.xref_table[row * 16 + r16];
+            return ldw<H16>(P.xref_table, row * 16 + r16);
         }
-        return P.xref[xref_off + i * 16];
+        return ldw<H16>(P.xref, xref_off + i * 16);
     };
-    const float x0 = P.xu[rowbase];
-    const float pterm = terminal_term<NX, NU, EXACT>(P.mats, r16, xref_at(N - 1));
+    const float x0 = ldw<H16>(P.xu, rowbase);
+    const float pterm = terminal_term<NX, NU, EXACT, H16>(P.mats, r16, xref_at(N - 1));
     int st = TINY_STATUS_UNSOLVED_, itn = 1;
     float r_ps = 0.f, r_pi = 0.f, r_ds = 0.f, r_di = 0.f;
     if (valid && !P.cold_start) // reset_workspace() zeroes the residual fields too
@@ -178,23 +176,23 @@ __global__ __launch_bounds__(WAVE) void admm_rowstream_kernel(const RowParams P)
             {
                 const int o = rowbase + i * 16;
                 float sv, xn = 0.f;
-                if (i < N - 1) lqr_step<NX, NU, EXACT>(G, is_x, is_u, s, zero_state ? 0.f : P.pd[o], sv, xn);
+                if (i < N - 1) lqr_step<NX, NU, EXACT, H16>(G, is_x, is_u, s, zero_state ? 0.f : ldw<H16>(P.pd, o), sv, xn);
                 else sv = is_x ? s : 0.f;
-                const float2 lh = bnd[i * 16 + r16];
-                const float a = zero_duals ? 0.f : P.gy[o];
-                const float bprev = zero_state ? 0.f : P.vz[o];
-                const float t = __builtin_amdgcn_fmed3f(sv + a, lh.x, lh.y);
-                const float an = (a + sv) - t;
+                const float2 lh = ld_bounds<H16>(P.bounds, i * 16 + r16);
+                const float a = zero_duals ? 0.f : ldw<H16>(P.gy, o);
+                const float bprev = zero_state ? 0.f : ldw<H16>(P.vz, o);
+                const float t = __builtin_amdgcn_fmed3f(rnd<H16>(sv + a), lh.x, lh.y);
+                const float an = rnd<H16>((a + sv) - t);
                 pri = fmaxf(pri, fabsf(sv - t));
                 dua = fmaxf(dua, fabsf(bprev - t));
-                P.vzn[o] = t;
-                P.gy[o] = an;
-                if (last_iter) P.xu[o] = sv;
+                stw<H16>(P.vzn, o, t);
+                stw<H16>(P.gy, o, an);
+                if (last_iter) stw<H16>(P.xu, o, sv);
                 t1 = t - an;
                 s = xn;
             }
-            const float pN = lin_cost<EXACT>(pterm, rho, t1);
-            P.pd[rowbase + (N - 1) * 16] = is_x ? pN : 0.f;
+            const float pN = lin_cost<EXACT, H16>(pterm, rho, t1);
+            stw<H16>(P.pd, rowbase + (N - 1) * 16, is_x ? pN : 0.f);
             const float pri_x = row_max(is_x ? pri : 0.f), dua_x = row_max(is_x ? dua : 0.f);
             const float pri_u = row_max(is_u ? pri : 0.f), dua_u = row_max(is_u ? dua : 0.f);
             itn = it + 1;
@@ -212,16 +210,16 @@ __global__ __launch_bounds__(WAVE) void admm_rowstream_kernel(const RowParams P)
             else
             {
                 float p = pN;
-                P.vz[rowbase + (N - 1) * 16] = P.vzn[rowbase + (N - 1) * 16];
+                stw<H16>(P.vz, rowbase + (N - 1) * 16, ldw<H16>(P.vzn, rowbase + (N - 1) * 16));
                 for (int i = N - 2; i >= 0; i--)
                 {
                     const int o = rowbase + i * 16;
-                    const float sni = P.vzn[o];
-                    const float cq = is_x ? -(xref_at(i) * qrow) : 0.f;
+                    const float sni = ldw<H16>(P.vzn, o);
+                    const float cq = is_x ? rnd<H16>(-(xref_at(i) * qrow)) : 0.f;
                     float pn, dd;
-                    riccati_step<NX, NU, EXACT>(G, is_x, p, lin_cost<EXACT>(cq, rho, sni - P.gy[o]), pn, dd);
-                    P.pd[o] = is_u ? dd : pn;
-                    P.vz[o] = sni;
+                    riccati_step<NX, NU, EXACT, H16>(G, is_x, p, lin_cost<EXACT, H16>(cq, rho, sni - ldw<H16>(P.gy, o)), pn, dd);
+                    stw<H16>(P.pd, o, is_u ? dd : pn);
+                    stw<H16>(P.vz, o, sni);
                     p = pn;
                 }
             }
@@ -245,13 +243,13 @@ __global__ __launch_bounds__(WAVE) void admm_rowstream_kernel(const RowParams P)
         {
             const int o = rowbase + i * 16;
             float sv, xn = 0.f;
-            if (i < N - 1) lqr_step<NX, NU, EXACT>(G, is_x, is_u, s, P.pd[o], sv, xn);
+            if (i < N - 1) lqr_step<NX, NU, EXACT, H16>(G, is_x, is_u, s, ldw<H16>(P.pd, o), sv, xn);
             else sv = is_x ? s : 0.f;
-            if (valid && solved) P.xu[o] = sv;
+            if (valid && solved) stw<H16>(P.xu, o, sv);
             s = xn;
-            const float cq = is_x ? -(xref_at(i) * qrow) : 0.f;
-            const float lin = lin_cost<EXACT>(cq, rho, P.vzn[o] - P.gy[o]);
-            if (valid) P.qr[o] = (i < N - 1 || is_x) ? lin : 0.f;
+            const float cq = is_x ? rnd<H16>(-(xref_at(i) * qrow)) : 0.f;
+            const float lin = lin_cost<EXACT, H16>(cq, rho, ldw<H16>(P.vzn, o) - ldw<H16>(P.gy, o));
+            if (valid) stw<H16>(P.qr, o, (i < N - 1 || is_x) ? lin : 0.f);
         }
         if (valid && r16 == 0)
         {
@@ -264,14 +262,18 @@ __global__ __launch_bounds__(WAVE) void admm_rowstream_kernel(const RowParams P)
     }
 }
 
-hipError_t launch_admm_rowstream(int nx, int nu, bool exact, const RowParams &P, hipStream_t stream)
+hipError_t launch_admm_rowstream(int nx, int nu, bool exact, bool h16, const RowParams &P, hipStream_t stream)
 {
     const int nblocks = (P.batch + 3) / 4;
+#define TINY_ROWSTREAM_LAUNCH(NX, NU, EX, H) \
+    hipLaunchKernelGGL((admm_rowstream_kernel<NX, NU, EX, H>), dim3(nblocks), dim3(WAVE), 0, stream, P)
 #define TINY_ROWSTREAM_DISPATCH(NX, NU)                                                                                \
     if (nx == NX && nu == NU)                                                                                          \
     {                                                                                                                  \
-        if (exact) hipLaunchKernelGGL((admm_rowstream_kernel<NX, NU, true>), dim3(nblocks), dim3(WAVE), 0, stream, P);  \
-        else hipLaunchKernelGGL((admm_rowstream_kernel<NX, NU, false>), dim3(nblocks), dim3(WAVE), 0, stream, P);      \
+        if (exact && !h16) TINY_ROWSTREAM_LAUNCH(NX, NU, true, false);                                                 \
+        else if (exact) TINY_ROWSTREAM_LAUNCH(NX, NU, true, true);                                                     \
+        else if (!h16) TINY_ROWSTREAM_LAUNCH(NX, NU, false, false);                                                    \
+        else TINY_ROWSTREAM_LAUNCH(NX, NU, false, true);                                                               \
         return hipGetLastError();                                                                                      \
     }
     TINY_FOR_EACH_ROWDIMS(TINY_ROWSTREAM_DISPATCH)
@@ -286,14 +288,18 @@ bool rowdims_supported(int nx, int nu)
     return false;
 }
 
-hipError_t launch_admm_step(int nx, int nu, bool exact, int fn, const RowParams &P, int *conv_out, hipStream_t stream)
+hipError_t launch_admm_step(int nx, int nu, bool exact, bool h16, int fn, const RowParams &P, int *conv_out, hipStream_t stream)
 {
     const int nblocks = (P.batch + 3) / 4;
+#define TINY_STEP_LAUNCH(NX, NU, EX, H) \
+    hipLaunchKernelGGL((admm_step_kernel<NX, NU, EX, H>), dim3(nblocks), dim3(WAVE), 0, stream, P, fn, conv_out)
 #define TINY_ROWDIMS_DISPATCH(NX, NU)                                                                                       \
     if (nx == NX && nu == NU)                                                                                               \
     {                                                                                                                       \
-        if (exact) hipLaunchKernelGGL((admm_step_kernel<NX, NU, true>), dim3(nblocks), dim3(WAVE), 0, stream, P, fn, conv_out);  \
-        else hipLaunchKernelGGL((admm_step_kernel<NX, NU, false>), dim3(nblocks), dim3(WAVE), 0, stream, P, fn, conv_out); \
+        if (exact && !h16) TINY_STEP_LAUNCH(NX, NU, true, false);                                                           \
+        else if (exact) TINY_STEP_LAUNCH(NX, NU, true, true);                                                               \
+        else if (!h16) TINY_STEP_LAUNCH(NX, NU, false, false);                                                              \
+        else TINY_STEP_LAUNCH(NX, NU, false, true);                                                                         \
         return hipGetLastError();                                                                                           \
     }
     TINY_FOR_EACH_ROWDIMS(TINY_ROWDIMS_DISPATCH)

@@ -85,6 +85,55 @@ __device__ __forceinline__ float row_max(float v)
     return v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Storage precision (template parameter H16 of the row kernels).  H16 = false: the work arrays are fp32, as in the
+// reference.  H16 = true ("fp16 storage, fp32 arithmetic", BASELINE.json configs[4]): every per-instance horizon array
+// (the twelve work arrays, Xref, the bounds) is IEEE binary16 in HBM; every ASSIGNMENT to a work array rounds the stored
+// value (round to nearest even, subnormals kept) and the fp32 registers carry that rounded value on; products, sums and
+// the residual reductions stay fp32.  oracle/ restates exactly this (the _h16 instantiation) and exact arithmetic is
+// bit-identical to it.
+// ---------------------------------------------------------------------------------------------
+template <bool H16>
+__device__ __forceinline__ float rnd(float v)
+{
+    if constexpr (H16)
+    {
+        // the fp32 result is rounded first, THEN stored as binary16 (what "fp16 storage" means).  Without the barrier
+        // hipcc folds fptrunc(fmul/fma) into v_fma_mixlo_f16, which rounds the exact product once, directly to binary16.
+        asm("" : "+v"(v));
+        return (float)(_Float16)v;
+    }
+    else return v;
+}
+template <bool H16>
+__device__ __forceinline__ float ldw(const float *base, int o)
+{
+    if constexpr (H16) return (float)reinterpret_cast<const _Float16 *>(base)[o];
+    else return base[o];
+}
+template <bool H16>
+__device__ __forceinline__ void stw(float *base, int o, float v)
+{
+    if constexpr (H16)
+    {
+        asm("" : "+v"(v)); // see rnd()
+        reinterpret_cast<_Float16 *>(base)[o] = (_Float16)v;
+    }
+    else base[o] = v;
+}
+// {lo, hi} entry e of the bounds table
+template <bool H16>
+__device__ __forceinline__ float2 ld_bounds(const float *base, int e)
+{
+    if constexpr (H16)
+    {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 v = reinterpret_cast<const h2 *>(base)[e];
+        return make_float2((float)v.x, (float)v.y);
+    }
+    else return reinterpret_cast<const float2 *>(base)[e];
+}
+
 template <int NX, int NU>
 struct RowPlans
 {
@@ -126,7 +175,7 @@ struct RowGains
 
 // forward_pass step (admm.cpp:31,35): from s = x_i (x rows) and ci = d_i (u rows) compute
 //   sv = [x_i ; u_i]  with u_i = -Kinf*x_i - d_i,   xn = x_{i+1} = Adyn*x_i + Bdyn*u_i (x rows)
-template <int NX, int NU, bool EXACT>
+template <int NX, int NU, bool EXACT, bool H16 = false>
 __device__ __forceinline__ void lqr_step(const RowGains<NX, NU> &G, bool is_x, bool is_u, float s, float ci, float &sv, float &xn)
 {
     using PL = RowPlans<NX, NU>;
@@ -137,25 +186,25 @@ __device__ __forceinline__ void lqr_step(const RowGains<NX, NU> &G, bool is_x, b
         float acc;
         if constexpr (PL::FWD_U == PL::FWD_XA) acc = reduce<PL::FWD_XA>(t);
         else acc = is_x ? reduce<PL::FWD_XA>(t) : reduce<PL::FWD_U>(t);
-        const float un = acc - ci; // the u rows of M1 hold -Kinf; negation is exact, so this is (-(K x)) - d bit for bit
+        const float un = rnd<H16>(acc - ci); // the u rows of M1 hold -Kinf; negation is exact, so this is (-(K x)) - d bit for bit
         float t2[NU];
         dpp_products<NX, NU>(t2, un, G.M2);
-        xn = acc + reduce<PL::FWD_XB>(t2);
+        xn = rnd<H16>(acc + reduce<PL::FWD_XB>(t2));
         sv = is_u ? un : s;
     }
     else
     {
         float acc = dpp_fma_dot<0, NX>(s, G.M1);
-        const float un = acc - ci;
+        const float un = rnd<H16>(acc - ci);
         dpp_fma_acc<NX, NU>(acc, un, G.M2);
-        xn = acc;
+        xn = rnd<H16>(acc);
         sv = is_u ? un : s;
     }
 }
 
 // backward_pass_grad step (admm.cpp:19-20): from p = p_{i+1} (x rows) and lin = [q_i ; r_i] compute
 //   pn = p_i = q_i + AmBKt*p_{i+1} - Kinf^T*r_i (x rows),   dd = d_i = Quu_inv*(Bdyn^T*p_{i+1} + r_i) (u rows)
-template <int NX, int NU, bool EXACT>
+template <int NX, int NU, bool EXACT, bool H16 = false>
 __device__ __forceinline__ void riccati_step(const RowGains<NX, NU> &G, bool is_x, float p, float lin, float &pn, float &dd)
 {
     using PL = RowPlans<NX, NU>;
@@ -170,29 +219,29 @@ __device__ __forceinline__ void riccati_step(const RowGains<NX, NU> &G, bool is_
         float tk[NU], td[NU];
         dpp_products<NX, NU>(tk, lin, G.M45);  // Kinf^T * r
         dpp_products<NX, NU>(td, wv, G.M45);   // Quu_inv * (Bdyn^T p + r)
-        pn = wv - reduce<PL::BWD_PK>(tk);
-        dd = reduce<PL::BWD_D>(td);
+        pn = rnd<H16>(wv - reduce<PL::BWD_PK>(tk));
+        dd = rnd<H16>(reduce<PL::BWD_D>(td));
     }
     else
     {
         float acc = lin;
         dpp_fma_acc<0, NX>(acc, p, G.M3);
-        dd = dpp_fma_dot<NX, NU>(acc, G.M45);  // u rows: Quu_inv
-        dpp_fma_acc<NX, NU>(acc, lin, G.M45);  // x rows: -Kinf^T
-        pn = acc;
+        dd = rnd<H16>(dpp_fma_dot<NX, NU>(acc, G.M45));  // u rows: Quu_inv
+        dpp_fma_acc<NX, NU>(acc, lin, G.M45);             // x rows: -Kinf^T
+        pn = rnd<H16>(acc);
     }
 }
 
 // [q_i ; r_i] of update_linear_cost (admm.cpp:80-82): cq = -(Xref_i .* Q) on x rows and 0 on u rows, t1 = snew - dual
-template <bool EXACT>
+template <bool EXACT, bool H16 = false>
 __device__ __forceinline__ float lin_cost(float cq, float rho, float t1)
 {
-    if constexpr (EXACT) return cq - rho * t1;
-    else return __builtin_fmaf(-rho, t1, cq);
+    if constexpr (EXACT) return rnd<H16>(cq - rho * t1);
+    else return rnd<H16>(__builtin_fmaf(-rho, t1, cq));
 }
 
 // -(Xref_{N-1}^T Pinf) (admm.cpp:83), x rows; PT[k] = Pinf(k, r)
-template <int NX, int NU, bool EXACT>
+template <int NX, int NU, bool EXACT, bool H16 = false>
 __device__ __forceinline__ float terminal_term(const float *mats, int r16, float xrN)
 {
     float PT[NX];
@@ -202,10 +251,10 @@ __device__ __forceinline__ float terminal_term(const float *mats, int r16, float
     {
         float t[NX];
         dpp_products<0, NX>(t, xrN, PT);
-        return -reduce<RowPlans<NX, NU>::TERM>(t);
+        return rnd<H16>(-reduce<RowPlans<NX, NU>::TERM>(t));
     }
     else
-        return -dpp_fma_dot<0, NX>(xrN, PT);
+        return rnd<H16>(-dpp_fma_dot<0, NX>(xrN, PT));
 }
 
 } // namespace tinympc

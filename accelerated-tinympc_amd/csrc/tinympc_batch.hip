@@ -79,10 +79,21 @@ __device__ __forceinline__ long long idx_of(int layout, const Geo g, int fam, in
     return layout == LAYOUT_ROW ? idx_row(g, fam, b, step, row) : idx_tile(g, fam, b, step, row);
 }
 
+// element access of a device-layout array: fp32, or IEEE binary16 when the handle stores fp16 (ROW layout only)
+__device__ __forceinline__ void put_elem(float *dst, long long i, float v, int h16)
+{
+    if (h16) reinterpret_cast<_Float16 *>(dst)[i] = (_Float16)v; // round to nearest even
+    else dst[i] = v;
+}
+__device__ __forceinline__ float get_elem(const float *src, long long i, int h16)
+{
+    return h16 ? (float)reinterpret_cast<const _Float16 *>(src)[i] : src[i];
+}
+
 // host-layout src [cnt][nsteps][dim] (cnt = 1: shared by all instances)  ->  device layout, steps [step0, step0+nsteps)
 // of instances [0, nb).  Rows/instances beyond the source are left untouched (they were zeroed at allocation).
 __global__ void pack_kernel(const float *__restrict__ src, float *__restrict__ dst, int layout, Geo g, int fam, int nb,
-                            int shared, int step0, int nsteps)
+                            int shared, int step0, int nsteps, int h16)
 {
     const int dim = fam ? g.nu : g.nx;
     const long long total = (long long)nb * nsteps * dim;
@@ -91,12 +102,12 @@ __global__ void pack_kernel(const float *__restrict__ src, float *__restrict__ d
         const int row = (int)(e % dim);
         const long long t = e / dim;
         const int s = (int)(t % nsteps), b = (int)(t / nsteps);
-        dst[idx_of(layout, g, fam, b, step0 + s, row)] = src[((long long)(shared ? 0 : b) * nsteps + s) * dim + row];
+        put_elem(dst, idx_of(layout, g, fam, b, step0 + s, row), src[((long long)(shared ? 0 : b) * nsteps + s) * dim + row], h16);
     }
 }
 
 __global__ void unpack_kernel(const float *__restrict__ src, float *__restrict__ dst, int layout, Geo g, int fam, int nb,
-                              int step0, int nsteps)
+                              int step0, int nsteps, int h16)
 {
     const int dim = fam ? g.nu : g.nx;
     const long long total = (long long)nb * nsteps * dim;
@@ -105,12 +116,12 @@ __global__ void unpack_kernel(const float *__restrict__ src, float *__restrict__
         const int row = (int)(e % dim);
         const long long t = e / dim;
         const int s = (int)(t % nsteps), b = (int)(t / nsteps);
-        dst[e] = src[idx_of(layout, g, fam, b, step0 + s, row)];
+        dst[e] = get_elem(src, idx_of(layout, g, fam, b, step0 + s, row), h16);
     }
 }
 
 // zero steps [step0, step0+nsteps) of one member of a device array
-__global__ void zero_kernel(float *__restrict__ dst, int layout, Geo g, int fam, int nb, int step0, int nsteps)
+__global__ void zero_kernel(float *__restrict__ dst, int layout, Geo g, int fam, int nb, int step0, int nsteps, int h16)
 {
     const int dim = fam ? g.nu : g.nx;
     const long long total = (long long)nb * nsteps * dim;
@@ -118,7 +129,7 @@ __global__ void zero_kernel(float *__restrict__ dst, int layout, Geo g, int fam,
     {
         const int row = (int)(e % dim);
         const long long t = e / dim;
-        dst[idx_of(layout, g, fam, (int)(t / nsteps), step0 + (int)(t % nsteps), row)] = 0.f;
+        put_elem(dst, idx_of(layout, g, fam, (int)(t / nsteps), step0 + (int)(t % nsteps), row), 0.f, h16);
     }
 }
 
@@ -126,7 +137,7 @@ __global__ void zero_kernel(float *__restrict__ dst, int layout, Geo g, int fam,
 // One thread per instance; matrices column-major in global memory (tiny, cache resident).
 __global__ void plant_step_kernel(float *__restrict__ x0buf, float *__restrict__ xarr, const float *__restrict__ uarr,
                                   const float *__restrict__ A, const float *__restrict__ Bm, int *__restrict__ wstart,
-                                  int window_advance, int batch, int layout, Geo g)
+                                  int window_advance, int batch, int layout, Geo g, int h16)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
@@ -138,13 +149,13 @@ __global__ void plant_step_kernel(float *__restrict__ x0buf, float *__restrict__
         float acc = 0.f;
         for (int k = 0; k < nx; k++) acc += A[k * nx + i] * x0[k];
         float acc2 = 0.f;
-        for (int m = 0; m < nu; m++) acc2 += Bm[m * nx + i] * uarr[idx_of(layout, g, 1, b, 0, m)];
+        for (int m = 0; m < nu; m++) acc2 += Bm[m * nx + i] * get_elem(uarr, idx_of(layout, g, 1, b, 0, m), h16);
         xn[i] = acc + acc2;
     }
     for (int i = 0; i < nx; i++)
     {
         x0buf[(long long)b * nx + i] = xn[i];
-        xarr[idx_of(layout, g, 0, b, 0, i)] = xn[i];
+        put_elem(xarr, idx_of(layout, g, 0, b, 0, i), xn[i], h16);
     }
     if (wstart && window_advance) wstart[b] += window_advance;
 }
@@ -182,6 +193,7 @@ struct TinyBatch
     bool row_dims_ok = false, tile_dims_ok = false, rowmath_ok = false;
     int *conv_dev = nullptr; // [batch] result of termination_condition
     hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr; // created by tiny_batch_group_solve for handles left on the null stream
     // problem class
     bool have_cache = false, have_dyn = false, have_settings = false, gains_dirty = true;
     float rho = 0.f;
@@ -199,6 +211,7 @@ struct TinyBatch
     float *t_xref = nullptr, *t_bnd[4] = {};              // TILE derived
     float *r_xref = nullptr, *r_bounds = nullptr;         // ROW derived
     float *tab_tile = nullptr, *tab_row = nullptr;        // trajectory table in both forms
+    float *tab_row_h = nullptr;                           // ... and [rows][16] binary16 for fp16 storage
     int table_rows = 0;
     int *xref_start = nullptr;
     int xref_mode = 0;
@@ -213,6 +226,7 @@ struct TinyBatch
     bool duals_zero_pending = false;
     bool cold_pending = false;
     int variant = VAR_AUTO;
+    bool h16 = false; // ROW-layout arrays, Xref and bounds stored as IEEE binary16 (tiny_batch_set_storage)
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -238,13 +252,14 @@ int dev_alloc_zero(float **p, size_t nfloats)
 }
 
 float *work_ptr(TinyBatch *tb, int id) { return tb->layout == LAYOUT_ROW ? tb->pair[kPairOf[id]] : tb->arr[id]; }
+int h16_of(const TinyBatch *tb, int layout) { return (tb->h16 && layout == LAYOUT_ROW) ? 1 : 0; }
 
 int alloc_layout(TinyBatch *tb, int layout)
 {
     if (layout == LAYOUT_ROW)
     {
         for (int p = 0; p < 6; p++)
-            if (!tb->pair[p]) TRY(dev_alloc_zero(&tb->pair[p], tb->pair_floats));
+            if (!tb->pair[p]) TRY(dev_alloc_zero(&tb->pair[p], tb->h16 ? (tb->pair_floats + 1) / 2 : tb->pair_floats));
     }
     else
     {
@@ -266,7 +281,7 @@ int launch_pack(TinyBatch *tb, const float *src, float *dst, int layout, int fam
 {
     const long long total = (long long)nb * nsteps * (fam ? tb->nu : tb->nx);
     hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(256), 0, tb->stream, src, dst, layout, geo(tb), fam, nb,
-                       shared ? 1 : 0, step0, nsteps);
+                       shared ? 1 : 0, step0, nsteps, h16_of(tb, layout));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -274,7 +289,7 @@ int launch_unpack(TinyBatch *tb, const float *src, float *dst, int layout, int f
 {
     const long long total = (long long)nb * nsteps * (fam ? tb->nu : tb->nx);
     hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(total)), dim3(256), 0, tb->stream, src, dst, layout, geo(tb), fam, nb,
-                       step0, nsteps);
+                       step0, nsteps, h16_of(tb, layout));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -282,7 +297,7 @@ int launch_zero(TinyBatch *tb, float *dst, int layout, int fam, int step0, int n
 {
     const long long total = (long long)tb->batch * nsteps * (fam ? tb->nu : tb->nx);
     hipLaunchKernelGGL(zero_kernel, dim3(grid_for(total)), dim3(256), 0, tb->stream, dst, layout, geo(tb), fam, tb->batch,
-                       step0, nsteps);
+                       step0, nsteps, h16_of(tb, layout));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -552,10 +567,23 @@ int prepare_inputs(TinyBatch *tb, int layout)
                 tab[((size_t)i * 16 + r) * 2 + 0] = lo < hi ? lo : hi;
                 tab[((size_t)i * 16 + r) * 2 + 1] = hi;
             }
-        TRY(upload_vec(tb, &tb->r_bounds, tab));
+        if (tb->h16) // same table in binary16 (bounds round to nearest; +-inf stays +-inf); half the floats
+        {
+            std::vector<_Float16> th(tab.size() + 1, (_Float16)0.f);
+            for (size_t e = 0; e < tab.size(); e++) th[e] = (_Float16)tab[e];
+            std::vector<float> packed((tab.size() + 1) / 2);
+            std::memcpy(packed.data(), th.data(), packed.size() * sizeof(float));
+            if (tb->r_bounds) { (void)hipFree(tb->r_bounds); tb->r_bounds = nullptr; }
+            TRY(upload_vec(tb, &tb->r_bounds, packed));
+        }
+        else
+        {
+            if (tb->r_bounds) { (void)hipFree(tb->r_bounds); tb->r_bounds = nullptr; }
+            TRY(upload_vec(tb, &tb->r_bounds, tab));
+        }
         const size_t nf = (size_t)(tb->in_xref.set && !tb->in_xref.shared ? tb->bpad4 : 1) * N * 16;
         if (tb->r_xref) { (void)hipFree(tb->r_xref); tb->r_xref = nullptr; }
-        TRY(dev_alloc_zero(&tb->r_xref, nf));
+        TRY(dev_alloc_zero(&tb->r_xref, tb->h16 ? (nf + 1) / 2 : nf));
         if (tb->in_xref.set)
             TRY(launch_pack(tb, tb->in_xref.dev, tb->r_xref, LAYOUT_ROW, 0, tb->in_xref.shared ? 1 : tb->batch, tb->in_xref.shared, 0, N));
     }
@@ -578,6 +606,8 @@ int resolve_variant(TinyBatch *tb, int *out)
     }
     if (v == VAR_STREAM && !tb->tile_dims_ok)
         return fail(TINY_BATCH_EUNSUPPORTED, "no streaming kernel instantiation for nx=%d nu=%d", tb->nx, tb->nu);
+    if (v == VAR_STREAM && tb->h16)
+        return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage is implemented by the row kernels only (nx + nu <= 16, batch-shared bounds)");
     *out = v;
     return 0;
 }
@@ -588,9 +618,10 @@ void update_kname(TinyBatch *tb)
     char nm[96];
     const std::string keep = g_err;
     if (resolve_variant(tb, &v)) { tb->kname = "unsupported"; g_err = keep; return; }
+    const char *ar = v == VAR_ROW_EXACT ? "exact" : "fast", *sto = tb->h16 ? ",h16" : "";
     if (v == VAR_STREAM) snprintf(nm, sizeof nm, "stream<%d,%d>", tb->NXC, tb->NUC);
-    else if (tb->row_dims_ok) snprintf(nm, sizeof nm, "rowlane<%d,%d,%d,%s>", tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT ? "exact" : "fast");
-    else snprintf(nm, sizeof nm, "rowstream<%d,%d,%s>", tb->nx, tb->nu, v == VAR_ROW_EXACT ? "exact" : "fast");
+    else if (tb->row_dims_ok) snprintf(nm, sizeof nm, "rowlane<%d,%d,%d,%s%s>", tb->nx, tb->nu, tb->N, ar, sto);
+    else snprintf(nm, sizeof nm, "rowstream<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
     tb->kname = nm;
 }
 
@@ -605,7 +636,7 @@ void fill_row_params(TinyBatch *tb, RowParams &P, bool exact)
     P.xu = tb->pair[0]; P.qr = tb->pair[1]; P.pd = tb->pair[2]; P.vz = tb->pair[3]; P.vzn = tb->pair[4]; P.gy = tb->pair[5];
     P.xref = tb->r_xref;
     P.xref_inst_stride = (tb->in_xref.set && !tb->in_xref.shared) ? (unsigned)tb->N * 16u : 0u;
-    P.xref_table = tb->tab_row; P.xref_start = tb->xref_start; P.table_rows = tb->table_rows;
+    P.xref_table = tb->h16 ? tb->tab_row_h : tb->tab_row; P.xref_start = tb->xref_start; P.table_rows = tb->table_rows;
     P.bounds = tb->r_bounds;
     P.mats = exact ? tb->mats_exact : tb->mats_fast;
     P.res = tb->res; P.status = tb->status; P.iter = tb->iter; P.n_unsolved = tb->n_unsolved;
@@ -629,7 +660,7 @@ int run_step(TinyBatch *tb, int fn, int *converged_host, int *n_true)
     RowParams P;
     fill_row_params(tb, P, tb->variant != VAR_ROW_FAST);
     HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, sizeof(int), tb->stream));
-    hipError_t e = launch_admm_step(tb->nx, tb->nu, tb->variant != VAR_ROW_FAST, fn, P, tb->conv_dev, tb->stream);
+    hipError_t e = launch_admm_step(tb->nx, tb->nu, tb->variant != VAR_ROW_FAST, tb->h16, fn, P, tb->conv_dev, tb->stream);
     if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
     if (fn == STEP_TERMINATION_CONDITION)
     {
@@ -694,8 +725,8 @@ int launch_solve(TinyBatch *tb)
     {
         RowParams P;
         fill_row_params(tb, P, v == VAR_ROW_EXACT);
-        e = tb->row_dims_ok ? launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, P, tb->stream)
-                            : launch_admm_rowstream(tb->nx, tb->nu, v == VAR_ROW_EXACT, P, tb->stream);
+        e = tb->row_dims_ok ? launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
+                            : launch_admm_rowstream(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream);
     }
     if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
     if (tb->timing)
@@ -783,10 +814,11 @@ void tiny_batch_destroy(TinyBatch *tb)
     (void)hipFree(tb->in_xref.dev);
     for (int k = 0; k < 4; k++) { (void)hipFree(tb->in_bnd[k].dev); (void)hipFree(tb->t_bnd[k]); }
     (void)hipFree(tb->t_xref); (void)hipFree(tb->r_xref); (void)hipFree(tb->r_bounds);
-    (void)hipFree(tb->tab_tile); (void)hipFree(tb->tab_row); (void)hipFree(tb->xref_start);
+    (void)hipFree(tb->tab_tile); (void)hipFree(tb->tab_row); (void)hipFree(tb->tab_row_h); (void)hipFree(tb->xref_start);
     (void)hipFree(tb->res); (void)hipFree(tb->status); (void)hipFree(tb->iter); (void)hipFree(tb->n_unsolved);
     (void)hipFree(tb->opnd); (void)hipFree(tb->qvec); (void)hipFree(tb->mats_exact); (void)hipFree(tb->mats_fast);
     (void)hipFree(tb->dA); (void)hipFree(tb->dB); (void)hipFree(tb->x0buf); (void)hipFree(tb->staging); (void)hipFree(tb->conv_dev);
+    if (tb->own_stream) (void)hipStreamDestroy(tb->own_stream);
     if (tb->ev0) (void)hipEventDestroy(tb->ev0);
     if (tb->ev1) (void)hipEventDestroy(tb->ev1);
     delete tb;
@@ -892,11 +924,18 @@ int tiny_batch_set_xref_window(TinyBatch *tb, const float *table, int rows, cons
         }
     if (tb->table_rows != rows)
     {
-        (void)hipFree(tb->tab_tile); (void)hipFree(tb->tab_row);
-        tb->tab_tile = tb->tab_row = nullptr;
+        (void)hipFree(tb->tab_tile); (void)hipFree(tb->tab_row); (void)hipFree(tb->tab_row_h);
+        tb->tab_tile = tb->tab_row = tb->tab_row_h = nullptr;
     }
     TRY(upload_vec(tb, &tb->tab_tile, tt));
     TRY(upload_vec(tb, &tb->tab_row, tr));
+    {
+        std::vector<_Float16> th(tr.size());
+        for (size_t e = 0; e < tr.size(); e++) th[e] = (_Float16)tr[e];
+        std::vector<float> packed(tr.size() / 2); // rows * 16 halves
+        std::memcpy(packed.data(), th.data(), packed.size() * sizeof(float));
+        TRY(upload_vec(tb, &tb->tab_row_h, packed));
+    }
     HIP_TRY(hipMemcpyAsync(tb->xref_start, start, (size_t)tb->batch * sizeof(int), hipMemcpyHostToDevice, tb->stream));
     HIP_TRY(hipStreamSynchronize(tb->stream));
     tb->table_rows = rows;
@@ -939,6 +978,41 @@ int tiny_batch_solve(TinyBatch *tb)
     int n = 0;
     TRY(tiny_batch_wait(tb, &n));
     return n > 0 ? 1 : 0;
+}
+
+// Mixed problem classes in one call (BASELINE.json configs[4]): every handle is one class (nx, nu, N, storage); all
+// solves are enqueued before any is waited for, each on its handle's stream, so they overlap on the device.
+int tiny_batch_group_solve(TinyBatch **tbs, int n, int *n_unsolved)
+{
+    CHECK_PTR(tbs);
+    if (n < 1) return fail(TINY_BATCH_EINVAL, "tiny_batch_group_solve: need at least one handle");
+    for (int i = 0; i < n; i++)
+    {
+        CHECK_TB(tbs[i]);
+        for (int j = 0; j < i; j++)
+            if (tbs[j] == tbs[i]) return fail(TINY_BATCH_EINVAL, "tiny_batch_group_solve: handle %d appears twice", i);
+    }
+    for (int i = 0; i < n; i++)
+    {
+        TinyBatch *tb = tbs[i];
+        if (!tb->stream) // the null stream would serialise the group
+        {
+            TRY(set_device(tb));
+            HIP_TRY(hipStreamSynchronize(nullptr)); // work already queued on the null stream (uploads) comes first
+            if (!tb->own_stream) HIP_TRY(hipStreamCreateWithFlags(&tb->own_stream, hipStreamNonBlocking));
+            tb->stream = tb->own_stream;
+        }
+        TRY(launch_solve(tb));
+    }
+    int total = 0;
+    for (int i = 0; i < n; i++)
+    {
+        int u = 0;
+        TRY(tiny_batch_wait(tbs[i], &u));
+        total += u;
+    }
+    if (n_unsolved) *n_unsolved = total;
+    return total > 0 ? 1 : 0;
 }
 
 int tiny_batch_forward_pass(TinyBatch *tb) { CHECK_TB(tb); return run_step(tb, STEP_FORWARD_PASS, nullptr, nullptr); }
@@ -1032,7 +1106,8 @@ int tiny_batch_mpc_step_async(TinyBatch *tb, int window_advance)
     TRY(tiny_batch_solve_async(tb));
     hipLaunchKernelGGL(plant_step_kernel, dim3((tb->batch + 127) / 128), dim3(128), 0, tb->stream, tb->x0buf,
                        work_ptr(tb, TINY_ARR_X), work_ptr(tb, TINY_ARR_U), tb->dA, tb->dB,
-                       tb->xref_mode == 1 ? tb->xref_start : nullptr, window_advance, tb->batch, tb->layout, geo(tb));
+                       tb->xref_mode == 1 ? tb->xref_start : nullptr, window_advance, tb->batch, tb->layout, geo(tb),
+                       h16_of(tb, tb->layout));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1069,6 +1144,32 @@ const char *tiny_batch_kernel_name(TinyBatch *tb)
     if (!tb) return "";
     update_kname(tb);
     return tb->kname.c_str();
+}
+
+int tiny_batch_set_storage(TinyBatch *tb, int bits)
+{
+    CHECK_TB(tb);
+    if (bits != 16 && bits != 32) return fail(TINY_BATCH_EINVAL, "storage must be 32 (fp32, default) or 16 (IEEE binary16)");
+    const bool want = bits == 16;
+    if (want == tb->h16) return 0;
+    if (want && !(tb->row_dims_ok || tb->rowmath_ok))
+        return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage is implemented by the row kernels only (nx=%d nu=%d has none)", tb->nx, tb->nu);
+    if (want && tb->variant == VAR_STREAM) return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage cannot be combined with the streaming kernel");
+    TRY(set_device(tb));
+    HIP_TRY(hipStreamSynchronize(tb->stream));
+    // the workspace restarts from zero in the new precision (like tiny_batch_create), inputs are re-derived
+    free_layout(tb, LAYOUT_TILE);
+    free_layout(tb, LAYOUT_ROW);
+    tb->h16 = want;
+    tb->layout = (want || tb->row_dims_ok || !tb->tile_dims_ok) ? LAYOUT_ROW : LAYOUT_TILE;
+    TRY(alloc_layout(tb, tb->layout));
+    HIP_TRY(hipMemsetAsync(tb->res, 0, (size_t)tb->batch * 4 * sizeof(float), tb->stream));
+    HIP_TRY(hipMemsetAsync(tb->status, 0, (size_t)tb->batch * sizeof(int), tb->stream));
+    HIP_TRY(hipMemsetAsync(tb->iter, 0, (size_t)tb->batch * sizeof(int), tb->stream));
+    HIP_TRY(hipMemsetAsync(tb->x0buf, 0, (size_t)tb->batch * tb->nx * sizeof(float), tb->stream));
+    tb->cold_pending = tb->duals_zero_pending = false;
+    tb->derived_dirty[0] = tb->derived_dirty[1] = true;
+    return 0;
 }
 
 int tiny_batch_select_kernel(TinyBatch *tb, int variant)

@@ -105,10 +105,11 @@ enum { STEP_FORWARD_PASS = 0, STEP_UPDATE_SLACK, STEP_UPDATE_DUAL, STEP_UPDATE_L
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 bool rowlane_supported(int nx, int nu, int N);
-hipError_t launch_admm_rowlane(int nx, int nu, int N, bool exact, const RowParams &P, hipStream_t stream);
+// h16: the row-layout arrays, Xref and the bounds table are IEEE binary16 (see rowlane_math.h: rnd/ldw/stw)
+hipError_t launch_admm_rowlane(int nx, int nu, int N, bool exact, bool h16, const RowParams &P, hipStream_t stream);
 bool rowdims_supported(int nx, int nu);
-hipError_t launch_admm_rowstream(int nx, int nu, bool exact, const RowParams &P, hipStream_t stream);
-hipError_t launch_admm_step(int nx, int nu, bool exact, int fn, const RowParams &P, int *conv_out, hipStream_t stream);
+hipError_t launch_admm_rowstream(int nx, int nu, bool exact, bool h16, const RowParams &P, hipStream_t stream);
+hipError_t launch_admm_step(int nx, int nu, bool exact, bool h16, int fn, const RowParams &P, int *conv_out, hipStream_t stream);
 
 hipError_t launch_admm_stream(int nxc, int nuc, const SolveParams &P, hipStream_t stream);
 

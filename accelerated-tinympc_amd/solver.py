@@ -66,7 +66,8 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch_set_x0_device": [P, P], "tiny_batch_get_u0_device": [P, P],
         "tiny_batch_mpc_step_async": [P, C.c_int], "tiny_batch_get_x0": [P, F],
         "tiny_batch_enable_timing": [P, C.c_int], "tiny_batch_last_solve_ms": [P, F],
-        "tiny_batch_select_kernel": [P, C.c_int],
+        "tiny_batch_select_kernel": [P, C.c_int], "tiny_batch_set_storage": [P, C.c_int],
+        "tiny_batch_group_solve": [C.POINTER(P), C.c_int, I],
         "tiny_riccati": [C.c_int, C.c_int, D, D, D, D, C.c_double, D, D, D, D, D, I],
     }
     for name, args in sig.items():
@@ -113,6 +114,18 @@ def riccati(nx, nu, A, B, Q, R, rho):
         raise TinyBatchError(f"tiny_riccati failed rc={rc}")
     return dict(Kinf=K.reshape(nx, nu).T.copy(), Pinf=Pm.reshape(nx, nx).T.copy(), Quu_inv=Qi.reshape(nu, nu).T.copy(),
                 AmBKt=Am.reshape(nx, nx).T.copy(), coeff_d2p=cd.reshape(nu, nx).T.copy(), iters=it.value)
+
+
+def solve_group(solvers) -> int:
+    """tiny_batch_group_solve: several problem classes (one TinyBatchSolver each) solved as one overlapping group.
+    Returns the number of instances, over all classes, that hit max_iter."""
+    lib = load_library()
+    hs = (C.c_void_p * len(solvers))(*[s._h for s in solvers])
+    n = C.c_int(0)
+    rc = lib.tiny_batch_group_solve(hs, len(solvers), C.byref(n))
+    if rc < 0:
+        raise TinyBatchError(f"rc={rc}: {lib.tiny_batch_last_error().decode()}")
+    return n.value
 
 
 class TinyBatchSolver:
@@ -287,6 +300,10 @@ class TinyBatchSolver:
 
     def select_kernel(self, variant: int):
         self._check(self.lib.tiny_batch_select_kernel(self._h, variant))
+
+    def set_storage(self, bits: int):
+        """32 = fp32 work arrays (default); 16 = IEEE binary16 storage with fp32 arithmetic.  Restarts the workspace."""
+        self._check(self.lib.tiny_batch_set_storage(self._h, bits))
 
     def set_stream(self, stream_ptr: int):
         self._check(self.lib.tiny_batch_set_stream(self._h, C.c_void_p(stream_ptr)))

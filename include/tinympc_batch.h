@@ -123,6 +123,13 @@ extern "C"
     /* wait for the stream; *n_unsolved = number of instances whose tiny_solve returned 1 */
     int tiny_batch_wait(TinyBatch *tb, int *n_unsolved);
 
+    /* ---- mixed problem classes in one call ---------------------------------------------------- */
+    /* Solves n handles (each one problem class: its own nx, nu, N, batch, storage precision) as one group: all
+     * launches are enqueued before any is waited for, each on its handle's stream (a handle still on the null stream
+     * is moved to a stream of its own), so the classes overlap on the device.  Returns 0 if every instance of every
+     * handle converged, 1 if some hit max_iter (*n_unsolved = how many, may be NULL), negative on error. */
+    int tiny_batch_group_solve(TinyBatch **tbs, int n, int *n_unsolved);
+
     /* ---- whole-workspace access (warm-start upload, parity tests) ---------------------------- */
     int tiny_batch_set_array(TinyBatch *tb, int array_id, const float *src);
     int tiny_batch_get_array(TinyBatch *tb, int array_id, float *dst);
@@ -146,10 +153,19 @@ extern "C"
     int tiny_batch_enable_timing(TinyBatch *tb, int on);
     /* Synchronises and returns the device time in ms of the most recent solve's kernel(s). */
     int tiny_batch_last_solve_ms(TinyBatch *tb, float *ms);
-    /* Name of the kernel variant the next solve will launch ("stream<3,1>", "resident<3,1,30>", ...). */
+    /* Name of the kernel variant the next solve will launch ("rowlane<12,4,30,exact>", "rowstream<12,4,fast>",
+     * "stream<3,1>", with ",h16" appended under fp16 storage). */
     const char *tiny_batch_kernel_name(TinyBatch *tb);
-    /* Force a kernel variant: 0 = auto, 1 = streaming (state in HBM), 2 = resident (state on chip). */
+    /* Force a kernel variant: 0 = auto (row kernels in exact arithmetic when the class has one and the bounds are
+     * batch-shared, else streaming), 1 = streaming MFMA kernel (state in HBM, fma arithmetic), 2 = row kernels, exact
+     * arithmetic (bitwise equal to the reference's SSE2 build), 3 = row kernels, fma arithmetic. */
     int tiny_batch_select_kernel(TinyBatch *tb, int variant);
+    /* Storage precision of the per-instance horizon arrays (the twelve work arrays, Xref, bounds) in HBM:
+     * 32 = fp32 like the reference (default); 16 = IEEE binary16 storage with fp32 arithmetic (BASELINE.json
+     * configs[4]): every assignment to a work array rounds to nearest even, products, sums and the four residual
+     * reductions stay fp32.  Row kernels only (nx + nu <= 16, batch-shared bounds).  Host-side arrays stay float; values
+     * are rounded when they are stored.  Changing the precision restarts the workspace from zero, like create. */
+    int tiny_batch_set_storage(TinyBatch *tb, int bits);
 
     /* ---- offline setup: Riccati cache precompute (src/tinympc/codegen.cpp:254-292), fp64, host ---- */
     /* A (nx x nx), B (nx x nu) column-major; Q (nx), R (nu) diagonals WITHOUT rho (the routine adds it,

@@ -51,10 +51,20 @@ def _ptr(a, ct):
 
 
 class _Dtype:
+    """np.float32 / np.float64 = the reference's arithmetic; the string "h16" = fp16 storage with fp32 arithmetic
+    (float32 arrays holding fp16-representable values; see the header of tinympc_oracle_impl.h)."""
+
     def __init__(self, dt):
-        self.np = np.dtype(dt)
+        self.h16 = isinstance(dt, str) and dt == "h16"
+        self.np = np.dtype(np.float32 if self.h16 else dt)
         self.ct = C.c_float if self.np == np.float32 else C.c_double
-        self.suf = "f32" if self.np == np.float32 else "f64"
+        self.suf = "h16" if self.h16 else ("f32" if self.np == np.float32 else "f64")
+
+
+def round_h16(a):
+    """What an fp16 store followed by a load leaves of float32 values (round to nearest even, subnormals kept)."""
+    with np.errstate(over="ignore"):
+        return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
 
 
 def _problem_struct(T):

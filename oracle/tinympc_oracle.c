@@ -32,6 +32,33 @@ static inline void oracle_apply_fp_mode(void) {}
 void oracle_set_ftz_daz(int on) { g_oracle_ftz = on; oracle_apply_fp_mode(); }
 
 
+/* float -> IEEE binary16 (round to nearest even, subnormals kept, overflow to infinity) -> float: the value an fp16
+ * store followed by a load leaves behind.  Bit-level, so it does not depend on compiler support for _Float16. */
+float oracle_round_h16(float f)
+{
+    union { float f; unsigned u; } v = {f};
+    const unsigned sign = v.u & 0x80000000u, a = v.u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return f;                     /* inf / nan */
+    if (a >= 0x477ff000u) { v.u = sign | 0x7f800000u; return v.f; } /* >= 65520 rounds to inf */
+    if (a < 0x38800000u)                                /* below 2^-14: fp16 subnormal, quantum 2^-24 */
+    {
+        union { float f; unsigned u; } m = {0};
+        m.u = a;
+        const float q = m.f * 16777216.0f;              /* exact scaling */
+        const float r = __builtin_rintf(q);             /* current rounding mode = to nearest even */
+        m.f = r * (1.0f / 16777216.0f);
+        v.u = sign | m.u;
+        return v.f;
+    }
+    /* normal: keep 10 mantissa bits */
+    const unsigned rem = a & 0x1fffu, base = a & ~0x1fffu;
+    unsigned res = base;
+    if (rem > 0x1000u || (rem == 0x1000u && (base & 0x2000u))) res += 0x2000u;
+    v.u = sign | res;
+    return v.f;
+}
+
+#define ST(x) (x)
 #define REAL float
 #define PS 4
 #define SUF(name) name##_f32
@@ -39,6 +66,19 @@ void oracle_set_ftz_daz(int on) { g_oracle_ftz = on; oracle_apply_fp_mode(); }
 #undef REAL
 #undef SUF
 #undef PS
+#undef ST
+
+/* fp16 storage / fp32 arithmetic (see the header of tinympc_oracle_impl.h) */
+#define ST(x) oracle_round_h16(x)
+#define REAL float
+#define PS 4
+#define SUF(name) name##_h16
+#include "tinympc_oracle_impl.h"
+#undef REAL
+#undef SUF
+#undef PS
+#undef ST
+#define ST(x) (x)
 
 #define REAL double
 #define PS 2

@@ -6,8 +6,12 @@
  * solver is the HIP library under accelerated-tinympc_amd/csrc and never calls
  * into this file.
  *
- * This header is a "template": it is included twice by tinympc_oracle.c, once with
- *   REAL=float  SUF(x)=x##_f32     and once with     REAL=double SUF(x)=x##_f64.
+ * This header is a "template": it is included three times by tinympc_oracle.c, with
+ *   REAL=float  SUF(x)=x##_f32,   REAL=double SUF(x)=x##_f64   (ST(x) = x: the reference's arithmetic), and
+ *   REAL=float  SUF(x)=x##_h16 with ST(x) = round-to-nearest-even to IEEE binary16 and back: "fp16 storage, fp32
+ *   arithmetic" (BASELINE.json configs[4]) — every ASSIGNMENT to a TinyWorkspace array member rounds the stored value,
+ *   products, sums, Eigen temporaries and the four residual reductions stay fp32.  The reference has no such mode, so
+ *   the _h16 instantiation is pinned only through the _f32 one it is textually identical to apart from ST().
  *
  * Every function names the reference lines it restates (paths relative to
  * /root/reference).  All matrices are column-major, exactly like the Eigen
@@ -153,10 +157,10 @@ void SUF(oracle_forward_pass)(const SUF(OracleProblem) * P, SUF(OracleWork) * W)
         REAL *xn = W->x + (size_t)(i + 1) * nx;
         /* u_i = -Kinf*x_i - d_i   (admm.cpp:31) */
         for (int j = 0; j < nu; j++)
-            ui[j] = -SUF(row_dot)(P->Kinf, nu, nx, j, xi) - di[j];
+            ui[j] = ST(-SUF(row_dot)(P->Kinf, nu, nx, j, xi) - di[j]);
         /* x_{i+1} = Adyn*x_i + Bdyn*u_i   (admm.cpp:35) */
         for (int j = 0; j < nx; j++)
-            xn[j] = SUF(row_dot)(P->Adyn, nx, nx, j, xi) + SUF(row_dot)(P->Bdyn, nx, nu, j, ui);
+            xn[j] = ST(SUF(row_dot)(P->Adyn, nx, nx, j, xi) + SUF(row_dot)(P->Bdyn, nx, nu, j, ui));
     }
 }
 
@@ -165,9 +169,9 @@ void SUF(oracle_update_slack)(const SUF(OracleProblem) * P, SUF(OracleWork) * W)
 {
     const int nxt = P->nx * P->N, nut = P->nu * (P->N - 1);
     for (int e = 0; e < nut; e++)
-        W->znew[e] = W->u[e] + W->y[e]; /* :47 */
+        W->znew[e] = ST(W->u[e] + W->y[e]); /* :47 */
     for (int e = 0; e < nxt; e++)
-        W->vnew[e] = W->x[e] + W->g[e]; /* :48 */
+        W->vnew[e] = ST(W->x[e] + W->g[e]); /* :48 */
     if (P->en_input_bound)              /* :51-54  u_max.cwiseMin(u_min.cwiseMax(znew)) */
         for (int e = 0; e < nut; e++)
         {
@@ -191,9 +195,9 @@ void SUF(oracle_update_dual)(const SUF(OracleProblem) * P, SUF(OracleWork) * W)
 {
     const int nxt = P->nx * P->N, nut = P->nu * (P->N - 1);
     for (int e = 0; e < nut; e++)
-        W->y[e] = W->y[e] + W->u[e] - W->znew[e];
+        W->y[e] = ST(W->y[e] + W->u[e] - W->znew[e]);
     for (int e = 0; e < nxt; e++)
-        W->g[e] = W->g[e] + W->x[e] - W->vnew[e];
+        W->g[e] = ST(W->g[e] + W->x[e] - W->vnew[e]);
 }
 
 /* src/tinympc/admm.cpp:77-85 */
@@ -203,21 +207,21 @@ void SUF(oracle_update_linear_cost)(const SUF(OracleProblem) * P, SUF(OracleWork
     const int nxt = nx * N, nut = nu * (N - 1);
     const REAL rho = P->rho;
     for (int e = 0; e < nut; e++)
-        W->r[e] = -rho * (W->znew[e] - W->y[e]); /* :80 */
+        W->r[e] = ST(-rho * (W->znew[e] - W->y[e])); /* :80 */
     for (int j = 0; j < N; j++)                  /* :81  q(i,j) = -(Xref(i,j)*Q(i)) */
         for (int i = 0; i < nx; i++)
-            W->q[(size_t)j * nx + i] = -(W->Xref[(size_t)j * nx + i] * P->Q[i]);
+            W->q[(size_t)j * nx + i] = ST(-(W->Xref[(size_t)j * nx + i] * P->Q[i]));
     for (int e = 0; e < nxt; e++)
-        W->q[e] -= rho * (W->vnew[e] - W->g[e]); /* :82 */
+        W->q[e] = ST(W->q[e] - rho * (W->vnew[e] - W->g[e])); /* :82 */
     /* :83  p.col(N-1) = -(Xref.col(N-1)^T * Pinf)  => p_j = -(sum_k Xref_k * Pinf(k,j)) */
     {
         const REAL *xr = W->Xref + (size_t)(N - 1) * nx;
         REAL *pN = W->p + (size_t)(N - 1) * nx;
         for (int j = 0; j < nx; j++)
-            pN[j] = -SUF(dot_vec)(xr, P->Pinf + (size_t)j * nx, nx); /* row-vector lazy product: coefficient-wise */
+            pN[j] = ST(-SUF(dot_vec)(xr, P->Pinf + (size_t)j * nx, nx)); /* row-vector lazy product: coefficient-wise */
         /* :84 */
         for (int j = 0; j < nx; j++)
-            pN[j] -= rho * (W->vnew[(size_t)(N - 1) * nx + j] - W->g[(size_t)(N - 1) * nx + j]);
+            pN[j] = ST(pN[j] - rho * (W->vnew[(size_t)(N - 1) * nx + j] - W->g[(size_t)(N - 1) * nx + j]));
     }
 }
 
@@ -272,8 +276,8 @@ void SUF(oracle_backward_pass_grad)(const SUF(OracleProblem) * P, SUF(OracleWork
         }
         for (int j = 0; j < nu; j++)
         {
-            if (gemv) di[j] = (REAL)0 + (REAL)1 * ((REAL)0 + SUF(dot_seq)(P->Quu_inv + j, nu, tmp, nu));
-            else      di[j] = SUF(row_dot)(P->Quu_inv, nu, nu, j, tmp);
+            if (gemv) di[j] = ST((REAL)0 + (REAL)1 * ((REAL)0 + SUF(dot_seq)(P->Quu_inv + j, nu, tmp, nu)));
+            else      di[j] = ST(SUF(row_dot)(P->Quu_inv, nu, nu, j, tmp));
         }
         /* p_i = q_i + AmBKt*p_{i+1} - Kinf^T*r_i   (admm.cpp:20; the coeff_d2p term is commented out there).
          * Kinf^T is a row-major view, so unless nu == 1 the expression is evaluated coefficient-wise. */
@@ -281,7 +285,7 @@ void SUF(oracle_backward_pass_grad)(const SUF(OracleProblem) * P, SUF(OracleWork
         {
             REAL a = p_packet ? SUF(dot_seq)(P->AmBKt + j, nx, pn, nx) : SUF(dot_novec)(P->AmBKt + j, nx, pn, nx);
             REAL k = SUF(dot_vec)(P->Kinf + (size_t)j * nu, ri, nu);
-            pi[j] = qi[j] + a - k;
+            pi[j] = ST(qi[j] + a - k);
         }
     }
 }

@@ -95,3 +95,38 @@ def test_riccati_oracle_vs_reference_codegen(oracle_mod):
         if nx == 4:
             assert it == 476  # "Kinf converged after 476 iterations" 
             np.testing.assert_allclose(c["Kinf"].ravel(), [-2.9121762, -4.8173684, 44.3538696, 19.7167444], atol=1e-7)
+
+
+def test_fp16_storage_oracle_rounding_and_fixpoint(oracle_mod):
+    """The _h16 instantiation (fp16 storage, fp32 arithmetic): its rounding primitive is IEEE binary16 round-to-nearest-even
+    (checked against numpy on normals, subnormals, ties and overflow), every array it leaves behind is binary16
+    representable, and with storage rounding switched off by construction (inputs that never leave the binary16 grid:
+    max_iter = 0) it touches nothing, like the fp32 oracle."""
+    import ctypes as C
+    O = oracle_mod
+    lib = O._lib()
+    lib.oracle_round_h16.argtypes, lib.oracle_round_h16.restype = [C.c_float], C.c_float
+    h = np.arange(0, 0x7c00, dtype=np.uint16).view(np.float16).astype(np.float32)
+    ties = ((h[:-1].astype(np.float64) + h[1:].astype(np.float64)) / 2).astype(np.float32)
+    rng = np.random.default_rng(0)
+    rand = (rng.standard_normal(20000) * 10.0 ** rng.integers(-9, 6, 20000)).astype(np.float32)
+    xs = np.concatenate([h[::7], ties[::5], -ties[::11], rand, np.array([65504, 65519.9, 65520, 1e6, -1e6, 0.0], np.float32)])
+    got = np.array([lib.oracle_round_h16(float(v)) for v in xs], np.float32)
+    assert np.array_equal(got, O.round_h16(xs))
+    import accelerated_tinympc_amd as T
+    prob = T.problems.quadrotor(20, 30)
+    B = 16
+    x0, table, start = T.problems.tracking_batch(B, 30, seed=1)
+    xref = O.round_h16(T.problems.expand_windows(table, start, 30))
+    bnds = tuple(O.round_h16(b) for b in T.problems.bounds_arrays(prob))
+    st = O.new_state(B, 12, 4, 30)
+    st["x"][:, 0] = O.round_h16(x0)
+    rc = O.Oracle(prob, "h16").solve(st, *bnds, xref)
+    assert 0 <= rc <= B and st["iter"].min() >= 2
+    for k in O.STATE_ORDER:
+        assert np.array_equal(st[k], O.round_h16(st[k])), k
+    st2 = O.copy_state(st)
+    O.Oracle(prob, "h16", dict(O.DEFAULT_SETTINGS, max_iter=0)).solve(st2, *bnds, xref)
+    for k in O.STATE_ORDER:
+        assert np.array_equal(st[k], st2[k])
+    assert np.all(st2["status"] == 11) and np.all(st2["iter"] == 1)

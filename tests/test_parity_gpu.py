@@ -698,3 +698,132 @@ def test_native_names_step_functions(tinympc, oracle_mod, case):
         for k in STATE_ORDER:
             assert np.array_equal(ns.a[k], st2[k][0]), f"tiny_solve max_iter={max_iter}: {k}"
         assert ns.work.iter == st2["iter"][0] and ns.work.status == st2["status"][0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fp16 storage with fp32 arithmetic (BASELINE.json configs[4]; tiny_batch_set_storage(16)).
+# Semantics: every per-instance horizon array is IEEE binary16 in HBM; each assignment to a work array rounds to nearest
+# even; products, sums and the four residual reductions are fp32.  The oracle's _h16 instantiation restates exactly that
+# (oracle/tinympc_oracle_impl.h: ST()), so the bar for EXACT arithmetic is unchanged: BITWISE equality with the oracle.
+# FAST arithmetic (fma) may differ from it in the last fp16 bit of a stored value, which 29 rounded roll-out steps and the
+# early exit amplify.  Its yardstick is the storage mode's own quantisation error, measured in the test: the fp32 oracle
+# run from the same (binary16-representable) live-in, used with the multipliers of the fp32 fast bar above.  Bar: the
+# fraction of instances whose iteration count differs from the _h16 oracle's <= max(1.5 x the fraction that differs
+# between fp16 storage and fp32, 2 %); the others agree with it within max(4 binary16 ulps of the array's magnitude
+# (2^-10 = 9.8e-4 each, the "~1e-3" SURVEY.md expects), 4 x the fp16-storage-vs-fp32 spread of the same array).
+# The iteration-count drift against fp32 storage is reported by tools/bench_configs.py, not bounded here.
+# ---------------------------------------------------------------------------------------------------------------------
+H16_CASES = {"quad30": ("quad", 30), "quad17": ("quad", 17), "cartpole10": ("cartpole", 10), "cartpole25": ("cartpole", 25)}
+
+
+@pytest.mark.parametrize("variant_name", ["row_exact", "row_fast"])
+@pytest.mark.parametrize("case", list(H16_CASES))
+def test_fp16_storage_vs_oracle(tinympc, oracle_mod, case, variant_name):
+    O, pr = oracle_mod, tinympc.problems
+    exact = VARIANTS[variant_name][1]
+    kind, N = H16_CASES[case]
+    prob = pr.quadrotor(20, N) if kind == "quad" else pr.cartpole(N)
+    nx, nu = prob["nx"], prob["nu"]
+    B = 203
+    rng = np.random.default_rng(N + nx)
+    x0 = rng.uniform(-0.3, 0.3, size=(B, nx)).astype(np.float32)
+    xref = (rng.standard_normal((B, N, nx)) * 0.1).astype(np.float32)
+    bnds = pr.bounds_arrays(prob)
+    settings = dict(O.DEFAULT_SETTINGS, max_iter=80)
+    sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+    sol.select_kernel(VARIANTS[variant_name][0])
+    sol.set_storage(16)
+    assert sol.kernel_name().endswith(",h16>"), sol.kernel_name()
+    sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
+    orc = O.Oracle(prob, "h16", settings)
+    bnds_h, xref_h = tuple(O.round_h16(b) for b in bnds), O.round_h16(xref)
+    st = O.new_state(B, nx, nu, N)
+    st["x"][:, 0] = O.round_h16(x0)
+    for k in range(3):  # cold start, then two warm starts with reset duals
+        st["y"][:] = 0; st["g"][:] = 0
+        sol.reset_dual_variables()
+        st32 = O.copy_state(st)
+        orc.solve(st, *bnds_h, xref_h, nthreads=8)
+        sol.solve()
+        got = sol.get_state()
+        for name in STATE_ORDER:
+            assert np.array_equal(got[name], O.round_h16(got[name])), f"{name} is not binary16-representable"
+        if exact:
+            assert_bitwise(got, st, f"h16 {case} k={k}")
+        else:
+            O.Oracle(prob, np.float32, settings).solve(st32, *bnds_h, xref_h, nthreads=8)  # the quantisation yardstick
+            same32 = st32["iter"] == st["iter"]
+            same = (got["iter"] == st["iter"]) & (got["status"] == st["status"])
+            f32flips = float((~same32).mean())
+            assert (~same).mean() <= max(1.5 * f32flips, 0.02) + 1.0 / B, \
+                f"h16 fast {case} k={k}: {(~same).mean():.2f} change the iteration count; fp16 storage itself changes {f32flips:.2f} vs fp32"
+            for name in STATE_ORDER:
+                scale = max(float(np.abs(st[name]).max()), 1e-2)
+                err = np.abs(got[name][same].astype(np.float64) - st[name][same]).max() / scale
+                sel = same32 if same32.any() else slice(None)
+                spread = np.abs(st32[name][sel].astype(np.float64) - st[name][sel]).max() / scale
+                assert err <= max(4 * 2.0 ** -10, 4 * spread), \
+                    f"h16 fast {case} k={k}: {name} off by {err:.2e} of its magnitude (storage spread {spread:.2e})"
+            sol.set_state(st)
+    # what the caller stores is rounded on the way in, and a state written back reads back identically
+    sol.set_array("d", st["d"] + np.float32(1e-4))
+    assert np.array_equal(sol.get_array("d"), O.round_h16(st["d"] + np.float32(1e-4)))
+    with pytest.raises(tinympc.TinyBatchError):
+        sol.select_kernel(1)  # the streaming kernel has no fp16 storage
+    sol.set_storage(32)       # back to fp32: workspace restarts from zero
+    assert not np.any(sol.get_array("d")) and not sol.kernel_name().endswith("h16>")
+    sol.close()
+
+
+def test_fp16_storage_step_functions(tinympc, oracle_mod):
+    """The six step functions under fp16 storage: each equals the oracle's _h16 restatement bit for bit."""
+    O, pr = oracle_mod, tinympc.problems
+    prob = pr.quadrotor(20, 17)
+    nx, nu, N, B = 12, 4, 17, 19
+    rng = np.random.default_rng(5)
+    bnds = tuple(O.round_h16(a * s) for a, s in zip(pr.bounds_arrays(prob), (0.2, 0.2, 1.0, 1.0)))
+    st = O.new_state(B, nx, nu, N)
+    for k in STATE_ORDER:
+        st[k][:] = O.round_h16(rng.standard_normal(st[k].shape) * 0.3)
+    st["iter"][:] = 2; st["status"][:] = 11
+    xref = O.round_h16(rng.standard_normal((B, N, nx)) * 0.3)
+    settings = dict(O.DEFAULT_SETTINGS, check_termination=2, abs_pri_tol=0.5, abs_dua_tol=5.0)
+    sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+    sol.set_storage(16)
+    sol.set_bounds(*bnds); sol.set_xref(xref)
+    orc = O.Oracle(prob, "h16", settings)
+    for fn in O.Oracle.STEP_FUNCTIONS:
+        sol.set_state(st)
+        ref_rv = orc.step(fn, st, *bnds, xref)
+        rv = getattr(sol, fn)()
+        if fn == "termination_condition":
+            assert np.array_equal(rv, ref_rv)
+        got = sol.get_state()
+        for k in STATE_ORDER + ("residuals",):
+            assert np.array_equal(got[k], st[k]), f"h16 {fn}: {k}"
+    sol.close()
+
+
+def test_mixed_size_group_solve_fp16(tinympc, oracle_mod):
+    """BASELINE.json configs[4] as one call: a cartpole class and a quadrotor class, both with fp16 storage, solved by
+    tiny_batch_group_solve; each class stays bitwise equal to its oracle, and the group result equals separate solves."""
+    O, pr = oracle_mod, tinympc.problems
+    sols, refs = [], []
+    for prob, B in ((pr.cartpole(10), 3001), (pr.quadrotor(20, 30), 2002)):
+        nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+        rng = np.random.default_rng(B)
+        x0 = rng.uniform(-0.2, 0.2, size=(B, nx)).astype(np.float32)
+        xref = np.zeros((N, nx), np.float32)
+        bnds = pr.bounds_arrays(prob)
+        settings = dict(O.DEFAULT_SETTINGS, max_iter=150)
+        sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+        sol.set_storage(16)
+        sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
+        st = O.new_state(B, nx, nu, N); st["x"][:, 0] = O.round_h16(x0)
+        O.Oracle(prob, "h16", settings).solve(st, *[O.round_h16(b) for b in bnds], xref, nthreads=8)
+        sols.append(sol); refs.append(st)
+    n_unsolved = tinympc.solve_group(sols)
+    assert n_unsolved == sum(int((st["status"] != 1).sum()) for st in refs)
+    for sol, st in zip(sols, refs):
+        assert_bitwise(sol.get_state(), st, "group " + sol.kernel_name())
+        sol.close()
