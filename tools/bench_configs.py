@@ -64,3 +64,41 @@ q17 = pr.quadrotor(20, 17)
 measure("any-N quadrotor N=17 65536", q17, 65536, track(65536, 17), (0, 3, 1))
 fixed = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=10)
 measure("cfg3 tracking fixed 10 iters", q30, 65536, track(65536), (0, 3, 1), settings=fixed)
+
+
+# ---- cfg5 as BASELINE.json states it: mixed cartpole + quadrotor batch in ONE call, fp16 storage / fp32 arithmetic ----
+def group(storage, variant, reps=5):
+    """32768 cartpole + 32768 quadrotor (tracking) instances solved by tiny_batch_group_solve; wall time of the group."""
+    import ctypes
+    sols, x0s = [], []
+    for prob, setup, st in ((cp, cps, dict(max_iter=150)), (q30, track(32768), None)):
+        sol = T.TinyBatchSolver(prob, 32768, settings=st)
+        sol.select_kernel(variant); sol.set_storage(storage)
+        sol.set_bounds(*pr.bounds_arrays(prob))
+        x0s.append(setup(sol)); sols.append(sol)
+    ts = []
+    for r in range(reps + 1):
+        for sol, x0 in zip(sols, x0s):
+            sol.reset_workspace(); sol.set_x0(x0)
+        for sol in sols: sol.synchronize()
+        t0 = time.perf_counter(); T.solve_group(sols); t1 = time.perf_counter()
+        if r: ts.append((t1 - t0) * 1e3)
+    out = []
+    for sol in sols:
+        it, stt, _ = sol.get_status()
+        out.append((sol.kernel_name(), it.copy(), float(np.mean(stt == 1)), sol.get_u()[:, 0].copy()))
+        sol.close()
+    ms = float(np.median(ts))
+    print(f"cfg5 mixed 32768 cartpole + 32768 quadrotor, storage fp{storage}, variant {variant}: {ms:7.3f} ms wall per group "
+          f"-> {65536 / ms * 1e3:.4g} solves/s; " + "; ".join(f"{k}: mean iters {i.mean():.2f}, converged {c:.3f}" for k, i, c, _ in out))
+    return out
+
+
+for variant in (2, 3):
+    ref = group(32, variant)
+    h16 = group(16, variant)
+    for (k32, i32, c32, u32), (k16, i16, c16, u16) in zip(ref, h16):
+        same = i32 == i16
+        du = np.abs(u16[same] - u32[same]).max() / max(np.abs(u32).max(), 1e-6) if same.any() else float("nan")
+        print(f"   fp16-storage drift of {k16}: iteration count differs for {np.mean(~same):.3f} of the instances "
+              f"(mean {i16.mean() - i32.mean():+.2f}); u0 of the others within {du:.2e} of the input scale")
