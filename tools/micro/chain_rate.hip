@@ -8,15 +8,16 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define D(k) " row_newbcast:" #k " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+// 256 threads = 4 waves = one per SIMD; dynamic LDS sized by the host so that exactly `waves/SIMD` workgroups fit a CU
 template <int MODE>
-__global__ __launch_bounds__(64) void k(float *out, const float *in, int iters, unsigned long long *clk)
+__global__ __launch_bounds__(256) void k(float *out, const float *in, int iters, unsigned long long *clk)
 {
-    __shared__ float pad[64];
+    extern __shared__ float pad[];
     const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
     float m[12];
-    for (int j = 0; j < 12; j++) m[j] = in[j * 64 + threadIdx.x];
     float x = in[threadIdx.x & 15], acc = 0.f, t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11;
     pad[threadIdx.x] = x;
+    for (int j = 0; j < 12; j++) m[j] = in[j * 64 + (threadIdx.x & 63)];
     for (int i = 0; i < iters; i++)
     {
         if constexpr (MODE == 0)
@@ -75,9 +76,48 @@ __global__ __launch_bounds__(64) void k(float *out, const float *in, int iters, 
                          : "=&v"(acc), "=&v"(t1), "=&v"(t2), "=&v"(t3)
                          : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]));
         }
+        else if constexpr (MODE == 5) // 11 dependent plain adds
+        {
+            asm volatile("v_add_f32 %0, %1, %2\n v_add_f32 %0, %0, %2\n v_add_f32 %0, %0, %2\n v_add_f32 %0, %0, %2\n v_add_f32 %0, %0, %2\n v_add_f32 %0, %0, %2\n"
+                         "v_add_f32 %0, %0, %2\n v_add_f32 %0, %0, %2\n v_add_f32 %0, %0, %2\n v_add_f32 %0, %0, %2\n v_add_f32 %0, %0, %2\n"
+                         : "=&v"(acc) : "v"(x), "v"(m[0]));
+        }
+        else if constexpr (MODE == 6) // 12 independent plain muls (no DPP)
+        {
+            asm volatile("v_mul_f32 %0, %12, %13\n v_mul_f32 %1, %12, %14\n v_mul_f32 %2, %12, %15\n v_mul_f32 %3, %12, %16\n v_mul_f32 %4, %12, %17\n v_mul_f32 %5, %12, %18\n"
+                         "v_mul_f32 %6, %12, %19\n v_mul_f32 %7, %12, %20\n v_mul_f32 %8, %12, %21\n v_mul_f32 %9, %12, %22\n v_mul_f32 %10, %12, %23\n v_mul_f32 %11, %12, %24\n"
+                         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(t8), "=&v"(t9), "=&v"(t10), "=&v"(t11)
+                         : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]));
+            acc = t11;
+        }
+        else if constexpr (MODE == 7) // 12 independent DPP muls only
+        {
+            asm volatile("s_nop 1\n"
+                         "v_mul_f32_dpp %0, %12, %13" D(0) "v_mul_f32_dpp %1, %12, %14" D(1) "v_mul_f32_dpp %2, %12, %15" D(2)
+                         "v_mul_f32_dpp %3, %12, %16" D(3) "v_mul_f32_dpp %4, %12, %17" D(4) "v_mul_f32_dpp %5, %12, %18" D(5)
+                         "v_mul_f32_dpp %6, %12, %19" D(6) "v_mul_f32_dpp %7, %12, %20" D(7) "v_mul_f32_dpp %8, %12, %21" D(8)
+                         "v_mul_f32_dpp %9, %12, %22" D(9) "v_mul_f32_dpp %10, %12, %23" D(10) "v_mul_f32_dpp %11, %12, %24" D(11)
+                         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(t8), "=&v"(t9), "=&v"(t10), "=&v"(t11)
+                         : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]));
+            acc = t11;
+        }
+        else if constexpr (MODE == 8) // exact, halving tree instead of SEQ (same instruction count, depth 4)
+        {
+            asm volatile("s_nop 1\n"
+                         "v_mul_f32_dpp %0, %12, %13" D(0) "v_mul_f32_dpp %1, %12, %14" D(1) "v_mul_f32_dpp %2, %12, %15" D(2)
+                         "v_mul_f32_dpp %3, %12, %16" D(3) "v_mul_f32_dpp %4, %12, %17" D(4) "v_mul_f32_dpp %5, %12, %18" D(5)
+                         "v_mul_f32_dpp %6, %12, %19" D(6) "v_mul_f32_dpp %7, %12, %20" D(7) "v_mul_f32_dpp %8, %12, %21" D(8)
+                         "v_mul_f32_dpp %9, %12, %22" D(9) "v_mul_f32_dpp %10, %12, %23" D(10) "v_mul_f32_dpp %11, %12, %24" D(11)
+                         "v_add_f32 %1, %1, %2\n v_add_f32 %4, %4, %5\n v_add_f32 %7, %7, %8\n v_add_f32 %10, %10, %11\n"
+                         "v_add_f32 %0, %0, %1\n v_add_f32 %3, %3, %4\n v_add_f32 %6, %6, %7\n v_add_f32 %9, %9, %10\n"
+                         "v_add_f32 %0, %0, %3\n v_add_f32 %6, %6, %9\n v_add_f32 %0, %0, %6\n"
+                         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(t8), "=&v"(t9), "=&v"(t10), "=&v"(t11)
+                         : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]));
+            acc = t0;
+        }
         x = acc; // the next block broadcasts this result
     }
-    out[blockIdx.x * 64 + threadIdx.x] = x + pad[(threadIdx.x + 1) & 63];
+    out[blockIdx.x * 256 + threadIdx.x] = x + pad[(threadIdx.x + 1) & 63];
     if (blockIdx.x == 0 && threadIdx.x == 0)
     {
         clk[0] = __builtin_readcyclecounter() - c0; // s_memtime
@@ -87,7 +127,9 @@ __global__ __launch_bounds__(64) void k(float *out, const float *in, int iters, 
 template <int MODE>
 void run(const char *name, float *d, const float *in, int waves_per_simd, int ninstr)
 {
-    const int blocks = 256 * 4 * waves_per_simd, iters = 100000;
+    const int blocks = 256 * waves_per_simd, iters = 100000;
+    const size_t lds = (160 * 1024) / waves_per_simd - 1024; // exactly waves_per_simd workgroups fit one CU
+    hipFuncSetAttribute((const void *)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     static unsigned long long *clk = nullptr;
     if (!clk) hipMalloc(&clk, 16);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -96,7 +138,7 @@ void run(const char *name, float *d, const float *in, int waves_per_simd, int ni
     for (int rep = 0; rep < 3; rep++) // the last repetition runs at settled clocks
     {
         hipEventRecord(a);
-        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, d, in, iters, clk);
+        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), lds, 0, d, in, iters, clk);
         hipEventRecord(b); hipEventSynchronize(b);
         hipEventElapsedTime(&ms, a, b);
         hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
@@ -120,6 +162,10 @@ int main()
         run<2>("F0 fast: 12 dependent fmac_dpp", d, in, w, 12);
         run<3>("F1 fast: two accumulators", d, in, w, 13);
         run<4>("F2 fast: four accumulators", d, in, w, 15);
+        run<5>("A  11 dependent plain adds", d, in, w, 11);
+        run<6>("M  12 independent plain muls", d, in, w, 12);
+        run<7>("P  12 independent mul_dpp", d, in, w, 12);
+        run<8>("E2 exact shape with a halving tree", d, in, w, 23);
     }
     return 0;
 }
