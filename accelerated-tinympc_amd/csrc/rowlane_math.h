@@ -134,6 +134,15 @@ __device__ __forceinline__ float2 ld_bounds(const float *base, int e)
     else return reinterpret_cast<const float2 *>(base)[e];
 }
 
+// max(acc, |d|) as ONE instruction: inside a rolled loop hipcc cannot prove the loop-carried maximum canonical and puts a
+// v_max_f32 acc, acc, acc in front of every fmaxf (acc is never a signalling NaN here: it starts at 0)
+__device__ __forceinline__ float max_abs(float acc, float d)
+{
+    float r;
+    asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(r) : "v"(acc), "v"(d));
+    return r;
+}
+
 template <int NX, int NU>
 struct RowPlans
 {

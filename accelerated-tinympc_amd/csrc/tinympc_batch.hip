@@ -190,7 +190,7 @@ struct TinyBatch
 {
     int nx = 0, nu = 0, N = 0, batch = 0, device = 0;
     int NXC = 0, NUC = 0, ntiles = 0, bpad4 = 0;
-    bool row_dims_ok = false, tile_dims_ok = false, rowmath_ok = false;
+    bool row_dims_ok = false, tile_dims_ok = false, rowmath_ok = false, rowloop_ok = false;
     int *conv_dev = nullptr; // [batch] result of termination_condition
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr; // created by tiny_batch_group_solve for handles left on the null stream
@@ -226,6 +226,7 @@ struct TinyBatch
     bool duals_zero_pending = false;
     bool cold_pending = false;
     int variant = VAR_AUTO;
+    int row_family_forced = -1; // tiny_batch_set_row_kernel
     bool h16 = false; // ROW-layout arrays, Xref and bounds stored as IEEE binary16 (tiny_batch_set_storage)
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -612,6 +613,17 @@ int resolve_variant(TinyBatch *tb, int *out)
     return 0;
 }
 
+// which of the three row kernels a row variant launches: 0 = unrolled register-resident (rowlane, fastest, one
+// instantiation per (nx, nu, N)), 1 = rolled-loop register-resident (rowloop, any N <= 32), 2 = any N with the state in
+// HBM (rowstream).  tiny_batch_set_row_kernel() can force one of them.
+int row_family(const TinyBatch *tb)
+{
+    if (tb->row_family_forced >= 0) return tb->row_family_forced;
+    if (tb->row_dims_ok) return 0;
+    if (tb->rowloop_ok) return 1;
+    return 2;
+}
+
 void update_kname(TinyBatch *tb)
 {
     int v = 0;
@@ -620,7 +632,8 @@ void update_kname(TinyBatch *tb)
     if (resolve_variant(tb, &v)) { tb->kname = "unsupported"; g_err = keep; return; }
     const char *ar = v == VAR_ROW_EXACT ? "exact" : "fast", *sto = tb->h16 ? ",h16" : "";
     if (v == VAR_STREAM) snprintf(nm, sizeof nm, "stream<%d,%d>", tb->NXC, tb->NUC);
-    else if (tb->row_dims_ok) snprintf(nm, sizeof nm, "rowlane<%d,%d,%d,%s%s>", tb->nx, tb->nu, tb->N, ar, sto);
+    else if (row_family(tb) == 0) snprintf(nm, sizeof nm, "rowlane<%d,%d,%d,%s%s>", tb->nx, tb->nu, tb->N, ar, sto);
+    else if (row_family(tb) == 1) snprintf(nm, sizeof nm, "rowloop<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
     else snprintf(nm, sizeof nm, "rowstream<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
     tb->kname = nm;
 }
@@ -725,8 +738,10 @@ int launch_solve(TinyBatch *tb)
     {
         RowParams P;
         fill_row_params(tb, P, v == VAR_ROW_EXACT);
-        e = tb->row_dims_ok ? launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
-                            : launch_admm_rowstream(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream);
+        const int fam = row_family(tb);
+        e = fam == 0   ? launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
+            : fam == 1 ? launch_admm_rowloop(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
+                       : launch_admm_rowstream(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream);
     }
     if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
     if (tb->timing)
@@ -783,6 +798,7 @@ int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int dev
     tb->NXC = nxc; tb->NUC = nuc; tb->ntiles = (batch + TILE - 1) / TILE; tb->bpad4 = (batch + 3) / 4 * 4;
     tb->tile_dims_ok = tile_ok; tb->row_dims_ok = row_ok;
     tb->rowmath_ok = rowdims_supported(nx, nu) && ((long long)(batch + 3) * N * 16 < (1ll << 30));
+    tb->rowloop_ok = tb->rowmath_ok && rowloop_supported(nx, nu, N);
     tb->xfam_floats = (size_t)tb->ntiles * N * WAVE * nxc;
     tb->ufam_floats = (size_t)tb->ntiles * (N - 1) * WAVE * nuc;
     tb->pair_floats = (size_t)tb->bpad4 * N * 16;
@@ -1144,6 +1160,17 @@ const char *tiny_batch_kernel_name(TinyBatch *tb)
     if (!tb) return "";
     update_kname(tb);
     return tb->kname.c_str();
+}
+
+int tiny_batch_set_row_kernel(TinyBatch *tb, int family)
+{
+    CHECK_TB(tb);
+    if (family < 0 || family > 3) return fail(TINY_BATCH_EINVAL, "row kernel must be 0 (auto), 1 (rowlane), 2 (rowloop) or 3 (rowstream)");
+    const bool ok = family == 0 || (family == 1 && tb->row_dims_ok) || (family == 2 && tb->rowloop_ok) || (family == 3 && tb->rowmath_ok);
+    if (!ok)
+        return fail(TINY_BATCH_EUNSUPPORTED, "row kernel %d has no instantiation for nx=%d nu=%d N=%d", family, tb->nx, tb->nu, tb->N);
+    tb->row_family_forced = family - 1;
+    return 0;
 }
 
 int tiny_batch_set_storage(TinyBatch *tb, int bits)

@@ -111,6 +111,10 @@ bool rowdims_supported(int nx, int nu);
 hipError_t launch_admm_rowstream(int nx, int nu, bool exact, bool h16, const RowParams &P, hipStream_t stream);
 hipError_t launch_admm_step(int nx, int nu, bool exact, bool h16, int fn, const RowParams &P, int *conv_out, hipStream_t stream);
 
+// rolled-loop register-resident kernel (admm_rowloop.hip): any N <= 32 for the (nx, nu) pairs of TINY_FOR_EACH_ROWDIMS
+bool rowloop_supported(int nx, int nu, int N);
+hipError_t launch_admm_rowloop(int nx, int nu, bool exact, bool h16, const RowParams &P, hipStream_t stream);
+
 hipError_t launch_admm_stream(int nxc, int nuc, const SolveParams &P, hipStream_t stream);
 
 } // namespace tinympc

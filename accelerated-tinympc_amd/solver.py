@@ -67,6 +67,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch_mpc_step_async": [P, C.c_int], "tiny_batch_get_x0": [P, F],
         "tiny_batch_enable_timing": [P, C.c_int], "tiny_batch_last_solve_ms": [P, F],
         "tiny_batch_select_kernel": [P, C.c_int], "tiny_batch_set_storage": [P, C.c_int],
+        "tiny_batch_set_row_kernel": [P, C.c_int],
         "tiny_batch_group_solve": [C.POINTER(P), C.c_int, I],
         "tiny_riccati": [C.c_int, C.c_int, D, D, D, D, C.c_double, D, D, D, D, D, I],
     }
@@ -300,6 +301,10 @@ class TinyBatchSolver:
 
     def select_kernel(self, variant: int):
         self._check(self.lib.tiny_batch_select_kernel(self._h, variant))
+
+    def set_row_kernel(self, family: int):
+        """0 auto, 1 rowlane (unrolled), 2 rowloop (rolled, N <= 32), 3 rowstream (state in HBM)."""
+        self._check(self.lib.tiny_batch_set_row_kernel(self._h, family))
 
     def set_storage(self, bits: int):
         """32 = fp32 work arrays (default); 16 = IEEE binary16 storage with fp32 arithmetic.  Restarts the workspace."""

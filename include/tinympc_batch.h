@@ -160,6 +160,10 @@ extern "C"
      * batch-shared, else streaming), 1 = streaming MFMA kernel (state in HBM, fma arithmetic), 2 = row kernels, exact
      * arithmetic (bitwise equal to the reference's SSE2 build), 3 = row kernels, fma arithmetic. */
     int tiny_batch_select_kernel(TinyBatch *tb, int variant);
+    /* Which row kernel variants 2/3 (and auto) launch: 0 = auto (1 where (nx,nu,N) has an unrolled instantiation, else 2 for
+     * N <= 32, else 3), 1 = rowlane (unrolled, state in registers/LDS), 2 = rowloop (rolled loops, state in registers/LDS,
+     * any N <= 32), 3 = rowstream (any N, state in HBM).  All three compute identical results. */
+    int tiny_batch_set_row_kernel(TinyBatch *tb, int family);
     /* Storage precision of the per-instance horizon arrays (the twelve work arrays, Xref, bounds) in HBM:
      * 32 = fp32 like the reference (default); 16 = IEEE binary16 storage with fp32 arithmetic (BASELINE.json
      * configs[4]): every assignment to a work array rounds to nearest even, products, sums and the four residual

@@ -33,8 +33,9 @@ PRIMAL_X = ("x", "v", "vnew")
 PRIMAL_U = ("u", "z", "znew")
 SCALARS = ("iter", "status", "residuals")
 
-# kernel variants under test: (select_kernel id, exact?)
-VARIANTS = {"row_exact": (2, True), "row_fast": (3, False), "stream": (1, False)}
+# kernel variants under test: (select_kernel id, exact?, set_row_kernel family: 0 auto = rowlane where instantiated)
+VARIANTS = {"row_exact": (2, True, 0), "row_fast": (3, False, 0), "stream": (1, False, 0),
+            "loop_exact": (2, True, 2), "loop_fast": (3, False, 2), "rowstream_exact": (2, True, 3)}
 
 
 def _floor(name, prob, ref):
@@ -93,6 +94,7 @@ def make_solver(T, prob, B, settings, xref, variant="stream", bnds=None):
     s = T.TinyBatchSolver(prob, B, settings=settings)
     try:
         s.select_kernel(VARIANTS[variant][0])
+        s.set_row_kernel(VARIANTS[variant][2])
     except T.TinyBatchError as e:
         s.close()
         pytest.skip(f"variant {variant} unavailable for nx={prob['nx']} nu={prob['nu']} N={prob['N']}: {e}")
@@ -512,11 +514,13 @@ def test_step_functions_individually(tinympc, oracle_mod, case, exact):
     sol.close()
 
 
-@pytest.mark.parametrize("case", [("quad", 5), ("quad", 17), ("quad", 45), ("cartpole", 25), ("odd", 12)])
+@pytest.mark.parametrize("case", [("quad", 5), ("quad", 17), ("quad", 32), ("quad", 33), ("quad", 45), ("cartpole", 25),
+                                  ("cartpole", 40), ("odd", 12), ("odd", 2)])
 @pytest.mark.parametrize("variant_name", ["row_exact", "row_fast"])
 def test_any_horizon_row_kernel(tinympc, oracle_mod, case, variant_name):
-    """Horizons without a register-resident instantiation run on the any-N row kernel (state in HBM): still bitwise
-    in exact arithmetic.  Cold start, then a warm start with reset duals; early exit."""
+    """Horizons without an unrolled instantiation: N <= 32 runs on the rolled-loop register-resident kernel (rowloop),
+    longer horizons on the any-N row kernel with the state in HBM (rowstream); both stay bitwise in exact arithmetic.
+    Cold start, then a warm start with reset duals; early exit."""
     O, pr = oracle_mod, tinympc.problems
     exact = VARIANTS[variant_name][1]
     kind, N = case
@@ -530,7 +534,7 @@ def test_any_horizon_row_kernel(tinympc, oracle_mod, case, variant_name):
     bnds = pr.bounds_arrays(prob)
     settings = dict(O.DEFAULT_SETTINGS, max_iter=60)
     sol = make_solver(tinympc, prob, B, settings, xref, variant_name, bnds)
-    assert sol.kernel_name().startswith("rowstream"), sol.kernel_name()
+    assert sol.kernel_name().startswith("rowloop" if N <= 32 else "rowstream"), sol.kernel_name()
     orc = O.Oracle(prob, np.float32, settings)
     st = O.new_state(B, nx, nu, N)
     st["x"][:, 0] = x0
@@ -713,7 +717,8 @@ def test_native_names_step_functions(tinympc, oracle_mod, case):
 # (2^-10 = 9.8e-4 each, the "~1e-3" SURVEY.md expects), 4 x the fp16-storage-vs-fp32 spread of the same array).
 # The iteration-count drift against fp32 storage is reported by tools/bench_configs.py, not bounded here.
 # ---------------------------------------------------------------------------------------------------------------------
-H16_CASES = {"quad30": ("quad", 30), "quad17": ("quad", 17), "cartpole10": ("cartpole", 10), "cartpole25": ("cartpole", 25)}
+H16_CASES = {"quad30": ("quad", 30), "quad17": ("quad", 17), "quad40": ("quad", 40), "cartpole10": ("cartpole", 10),
+             "cartpole25": ("cartpole", 25)}  # rowlane, rowloop, rowstream, rowlane, rowloop
 
 
 @pytest.mark.parametrize("variant_name", ["row_exact", "row_fast"])
