@@ -113,7 +113,9 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
     for (int it = 0; it < P.max_iter; ++it)
     {
         if (!__any(active)) break;
-        const bool last_iter = (it == P.max_iter - 1);
+        // the last permitted iteration must not overwrite d in registers: x,u of an instance that exhausts max_iter come
+        // from the d its last forward sweep used (regenerated in the epilogue); the final d itself is in the pd array
+        const bool keep_d = (it == P.max_iter - 1);
         if (active)
         {
             // ---------------- forward sweep: forward_pass + update_slack + update_dual + residual maxima ----------------
@@ -136,7 +138,6 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
                 pri = fmaxf(pri, fabsf(sv - t));           // admm.cpp:95,97
                 dua = fmaxf(dua, fabsf(b_pref - t));       // admm.cpp:96,98
                 sn[i * WAVE] = t;
-                if (last_iter) stw<H16>(P.xu, rowbase + i * 16, sv); // x,u of an instance that exhausts max_iter
                 s = xn;
                 lh = lh_next;
                 b_pref = b_next;
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
                 float p = pN;
                 b[(N - 1) * WAVE] = sn[(N - 1) * WAVE];
                 ran_bwd = true;
+                const bool upd_d = is_u && !keep_d;
                 float sn_pref = sn[(N - 2) * WAVE];
 #pragma unroll
                 for (int i = N - 2; i >= 0; i--)
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
                     const float cq = c[i] * maskx;         // x rows: -(Xref.*Q) ; u rows: 0 (x*1 and d*0 are exact)
                     float pn, dd;
                     riccati_step<NX, NU, EXACT, H16>(G, is_x, p, lin_cost<EXACT, H16>(cq, rho, t1), pn, dd); // admm.cpp:19-20,80-82
-                    c[i] = is_u ? dd : c[i];
+                    c[i] = upd_d ? dd : c[i];
                     b[i * WAVE] = sni;                     // admm.cpp:141-142
                     stw<H16>(P.pd, rowbase + i * 16, is_u ? dd : pn); // [p_i ; d_i] of this sweep
                     p = pn;
@@ -205,11 +207,11 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
         for (int i = 0; i < N; i++)
         {
             const int o = rowbase + i * 16;
-            // x,u of a converged instance: regenerated from its frozen d by the same instruction sequence
+            // x,u: regenerated from the d of the last executed forward sweep by the same instruction sequence
             float sv, xn = 0.f;
             if (i < N - 1) lqr(s, c[i], sv, xn);
             else sv = is_x ? s : 0.f;
-            if (solved) stw<H16>(P.xu, o, sv);
+            stw<H16>(P.xu, o, sv);
             s = xn;
             const float sni = sn[i * WAVE];
             const float t1 = sni - a[i];
