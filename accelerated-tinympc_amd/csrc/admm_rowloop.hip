@@ -9,10 +9,11 @@
 //     The replaced value is streamed to the vz array: if THIS iteration converges tiny_solve returns before v = vnew
 //     (admm.cpp:135-142) and the stash is the live-out v | z, otherwise the epilogue overwrites it.  Like [p ; d] the
 //     repeated overwrites of the same lines are absorbed by L2 / Infinity Cache.
-// Register and LDS footprint (~130 VGPRs, 384 B of LDS per horizon step and wave) allow 3 waves per SIMD where the
-// unrolled kernel fits 2; rocprof shows the unrolled kernel bound by the per-wave issue rate, so the
-// extra ~25 % instructions of the loop and index bookkeeping are paid for by the third wave.
-// N is a run-time value: one instantiation per (nx, nu) serves every horizon up to 32.
+// Register and LDS footprint (~145 VGPRs, 384 B of LDS per horizon step and wave) allow 3 waves per SIMD where the
+// unrolled kernel fits 2, but the loop and index bookkeeping cost ~45 % more instructions per step: at N = 30 it is 13 %
+// slower than the unrolled kernel, which therefore stays the default where it is instantiated.
+// N is a run-time value: one instantiation per (nx, nu) serves every horizon up to 32 — 1.9x faster than streaming the
+// state through HBM (admm_rowstream_kernel).
 #include "rowlane_math.h"
 
 namespace tinympc
