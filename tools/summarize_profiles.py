@@ -11,10 +11,9 @@ prof = ROOT / "profiles"
 
 
 def counter_rows(d):
-    rows = []
-    for f in glob.glob(str(src / d / "**" / "*counter_collection.csv"), recursive=True):
-        rows += list(csv.DictReader(open(f)))
-    return rows
+    # gpurun merges every call's files into the same directory: only the newest collection of a pass counts
+    files = sorted(glob.glob(str(src / d / "**" / "*counter_collection.csv"), recursive=True), key=lambda f: Path(f).stat().st_mtime)
+    return list(csv.DictReader(open(files[-1]))) if files else []
 
 
 def per_kernel(rows, counter):
@@ -57,16 +56,18 @@ for l in open(src / "bench_stats.log"):
 out["bench_line_under_profiler"] = line
 kshort = (line["roofline"]["kernel"] if line else "kernel").replace("<", "_").replace(">", "").replace(",", "_")
 (prof / f"{tag}_{kshort}_pmc.json").write_text(json.dumps(out, indent=1))
-for f in glob.glob(str(src / "stats" / "**" / "*kernel_stats.csv"), recursive=True):
-    (prof / f"{tag}_{kshort}_kernel_stats.csv").write_text(open(f).read())
+stats = sorted(glob.glob(str(src / "stats" / "**" / "*kernel_stats.csv"), recursive=True), key=lambda f: Path(f).stat().st_mtime)
+if stats:
+    (prof / f"{tag}_{kshort}_kernel_stats.csv").write_text(open(stats[-1]).read())
 # the table bench.py reads: "<kernel name>:<mode>:<batch>" -> HBM bytes per launch
 tf = prof / "hbm_traffic.json"
 table = json.loads(tf.read_text()) if tf.exists() else {}
+table = {k: v for k, v in table.items() if not k.startswith("void ")}
 def label(kname):
     import re
-    m = re.search(r"admm_rowlane_kernel<(\d+), (\d+), (\d+), (true|false)>", kname)
+    m = re.search(r"admm_rowlane_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)>", kname)
     if m:
-        return f"rowlane<{m.group(1)},{m.group(2)},{m.group(3)},{'exact' if m.group(4) == 'true' else 'fast'}>"
+        return f"rowlane<{m.group(1)},{m.group(2)},{m.group(3)},{'exact' if m.group(4) == 'true' else 'fast'}{',h16' if m.group(5) == 'true' else ''}>"
     m = re.search(r"admm_stream_kernel<(\d+), (\d+)>", kname)
     return f"stream<{m.group(1)},{m.group(2)}>" if m else kname
 if line:
