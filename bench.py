@@ -174,6 +174,28 @@ def main():
     iters, status, _ = sol.get_status()
     agg = T.sharding.reduce_stats(dist, "cuda" if backend == "nccl" else "cpu", iters, status, flops_of(iters, status), dt)
     dt = agg["wall_s"]  # max over ranks
+    # optional epilogue of SURVEY.md §8(e), outside the timed region: every rank obtains u.col(0) of all instances with
+    # one all-gather (nu floats per instance; RCCL over xGMI on the real runs).  Never allowed to break the bench line.
+    gather = None
+    if dist is not None:
+        try:
+            d_u0 = torch.empty((B, NU), dtype=torch.float32, device="cuda")
+            sol._check(lib.tiny_batch_get_u0_device(h, C.c_void_p(d_u0.data_ptr())))
+            sol.synchronize()
+            t_g = time.perf_counter()
+            if backend == "nccl":
+                d_all = torch.empty((B * world, NU), dtype=torch.float32, device="cuda")
+                dist.all_gather_into_tensor(d_all, d_u0)
+                torch.cuda.synchronize()
+                mine = d_all[rank * B:(rank + 1) * B]
+            else:
+                outs = [torch.empty((B, NU), dtype=torch.float32) for _ in range(world)]
+                dist.all_gather(outs, d_u0.cpu())
+                mine = outs[rank].cuda()
+            gather = {"op": "all_gather of u.col(0)", "bytes_per_rank": B * NU * 4, "ms": (time.perf_counter() - t_g) * 1e3,
+                      "own_block_intact": bool(torch.equal(mine, d_u0))}
+        except Exception as e:  # noqa: BLE001
+            gather = {"error": f"{type(e).__name__}: {e}"}
     total_solves = B * world * args.steps
     value = total_solves / dt
     # the opt-in fma-chain arithmetic of the same kernel, for reference (not the headline: see DESIGN.md §3)
@@ -230,6 +252,8 @@ def main():
         }
         if fast is not None:
             line["fast_arithmetic"] = fast
+        if gather is not None:
+            line["final_gather"] = gather
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(prob, pr)
         print(json.dumps(line), flush=True)
