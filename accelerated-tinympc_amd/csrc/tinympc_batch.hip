@@ -1106,6 +1106,49 @@ int tiny_batch_reset_workspace(TinyBatch *tb)
     return 0;
 }
 
+// Device-pointer forms of set_array / get_array / set_xref: same host-layout arrays ([B][N][nx] / [B][N-1][nu], fp32),
+// but resident in device memory on the handle's device; converted to/from the private layout by one kernel on the
+// handle's stream, no host round trip and no synchronisation.
+int tiny_batch_set_array_device(TinyBatch *tb, int id, const float *d_src)
+{
+    CHECK_TB(tb); CHECK_PTR(d_src);
+    if (id < 0 || id >= TINY_ARR_COUNT) return fail(TINY_BATCH_EINVAL, "bad array id %d", id);
+    TRY(set_device(tb));
+    TRY(flush_pending(tb));
+    const int fam = is_xfam(id) ? 0 : 1;
+    TRY(launch_pack(tb, d_src, work_ptr(tb, id), tb->layout, fam, tb->batch, false, 0, fam ? tb->N - 1 : tb->N));
+    if (id == TINY_ARR_X) TRY(launch_unpack(tb, work_ptr(tb, TINY_ARR_X), tb->x0buf, tb->layout, 0, tb->batch, 0, 1));
+    return 0;
+}
+
+int tiny_batch_get_array_device(TinyBatch *tb, int id, float *d_dst)
+{
+    CHECK_TB(tb); CHECK_PTR(d_dst);
+    if (id < 0 || id >= TINY_ARR_COUNT) return fail(TINY_BATCH_EINVAL, "bad array id %d", id);
+    TRY(set_device(tb));
+    TRY(flush_pending(tb));
+    const int fam = is_xfam(id) ? 0 : 1;
+    return launch_unpack(tb, work_ptr(tb, id), d_dst, tb->layout, fam, tb->batch, 0, fam ? tb->N - 1 : tb->N);
+}
+
+int tiny_batch_set_xref_device(TinyBatch *tb, const float *d_xref, int shared)
+{
+    CHECK_TB(tb); CHECK_PTR(d_xref);
+    TRY(set_device(tb));
+    InputArr &in = tb->in_xref;
+    const bool sh = shared != 0;
+    const size_t n = (size_t)(sh ? 1 : tb->batch) * tb->N * tb->nx;
+    if (in.dev && in.shared != sh) { (void)hipFree(in.dev); in.dev = nullptr; }
+    if (!in.dev) HIP_TRY(hipMalloc((void **)&in.dev, n * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(in.dev, d_xref, n * sizeof(float), hipMemcpyDeviceToDevice, tb->stream));
+    in.shared = sh;
+    in.set = true;
+    in.host.clear(); // only the bounds are ever read on the host
+    tb->derived_dirty[0] = tb->derived_dirty[1] = true;
+    tb->xref_mode = 0;
+    return 0;
+}
+
 int tiny_batch_get_u0_device(TinyBatch *tb, float *d_u0)
 {
     CHECK_TB(tb); CHECK_PTR(d_u0);

@@ -69,6 +69,8 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch_select_kernel": [P, C.c_int], "tiny_batch_set_storage": [P, C.c_int],
         "tiny_batch_set_row_kernel": [P, C.c_int],
         "tiny_batch_group_solve": [C.POINTER(P), C.c_int, I],
+        "tiny_batch_set_array_device": [P, C.c_int, P], "tiny_batch_get_array_device": [P, C.c_int, P],
+        "tiny_batch_set_xref_device": [P, P, C.c_int],
         "tiny_riccati": [C.c_int, C.c_int, D, D, D, D, C.c_double, D, D, D, D, D, I],
     }
     for name, args in sig.items():

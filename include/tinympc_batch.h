@@ -140,6 +140,11 @@ extern "C"
     /* ---- device-pointer forms (no host round trip) ------------------------------------------ */
     int tiny_batch_set_x0_device(TinyBatch *tb, const float *d_x0 /*[B][nx]*/);
     int tiny_batch_get_u0_device(TinyBatch *tb, float *d_u0 /*[B][nu] = u.col(0) of every instance*/);
+    /* set_array / get_array / set_xref with DEVICE pointers (same array-of-instances fp32 layout, memory on the handle's
+     * device): one conversion kernel on the handle's stream, asynchronous. */
+    int tiny_batch_set_array_device(TinyBatch *tb, int array_id, const float *d_src);
+    int tiny_batch_get_array_device(TinyBatch *tb, int array_id, float *d_dst);
+    int tiny_batch_set_xref_device(TinyBatch *tb, const float *d_xref /*[B][N][nx] or [N][nx]*/, int shared);
 
     /* ---- closed loop on the device (quadrotor_hovering.cpp:90-114 / quadrotor_tracking.cpp:93-118) ------
      * One MPC step for every instance without touching the host:

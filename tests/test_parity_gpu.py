@@ -832,3 +832,41 @@ def test_mixed_size_group_solve_fp16(tinympc, oracle_mod):
     for sol, st in zip(sols, refs):
         assert_bitwise(sol.get_state(), st, "group " + sol.kernel_name())
         sol.close()
+
+
+def test_device_pointer_io_equals_host_io(tinympc):
+    """set_xref_device / set_array_device / get_array_device (device-resident fp32 arrays in the ABI layout, no host round
+    trip) give bit-identical results to the host-pointer calls."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    pr = tinympc.problems
+    prob = pr.quadrotor(20, 30)
+    B, N, nx, nu = 517, 30, 12, 4
+    x0, table, start = pr.tracking_batch(B, N, seed=4)
+    xref = pr.expand_windows(table, start, N)
+    xfull = np.zeros((B, N, nx), np.float32); xfull[:, 0] = x0
+
+    def dev(a):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(a.nbytes)) == 0
+        assert hip.hipMemcpy(p, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(a.nbytes), 1) == 0  # H2D
+        return p
+
+    ref = tinympc.TinyBatchSolver(prob, B)
+    ref.set_bounds(*pr.bounds_arrays(prob)); ref.set_xref(xref); ref.set_x0(x0); ref.solve()
+    sol = tinympc.TinyBatchSolver(prob, B)
+    sol.set_bounds(*pr.bounds_arrays(prob))
+    d_xref, d_x = dev(xref), dev(xfull)
+    sol._check(sol.lib.tiny_batch_set_xref_device(sol._h, d_xref, 0))
+    sol._check(sol.lib.tiny_batch_set_array_device(sol._h, tinympc.ARRAY_IDS["x"], d_x))
+    sol.solve()
+    u = np.empty((B, N - 1, nu), np.float32)
+    d_u = dev(u)
+    sol._check(sol.lib.tiny_batch_get_array_device(sol._h, tinympc.ARRAY_IDS["u"], d_u))
+    sol.synchronize()
+    assert hip.hipMemcpy(u.ctypes.data_as(ctypes.c_void_p), d_u, ctypes.c_size_t(u.nbytes), 2) == 0  # D2H
+    assert np.array_equal(u, ref.get_u()) and np.array_equal(sol.get_x(), ref.get_x())
+    assert np.array_equal(sol.get_status()[0], ref.get_status()[0])
+    for p in (d_xref, d_x, d_u):
+        hip.hipFree(p)
+    sol.close(); ref.close()
