@@ -1,0 +1,314 @@
+// admm_wave.hip — exact-arithmetic batched TinyMPC ADMM kernel for problem classes with 16 < nx + nu <= 64
+// (BASELINE.json configs[3]: nx = 32, nu = 16, N = 50): ONE WAVEFRONT = ONE INSTANCE.
+//
+// Restates tiny_solve() (src/tinympc/admm.cpp:111-152) like admm_rowstream_kernel, with the row mapping widened from a
+// DPP row to the whole wave: lane r owns row r of the stacked vector [x ; u] (r < NX: x(r), NX <= r < NX+NU: u(r-NX)).
+// A gain x state product broadcasts the state vector through LDS (one ds_write_b32, then 16-byte broadcast reads) and is
+// one plain v_mul_f32 per column with the lane's own gain entry; the sums follow the orders the reference's SSE2 Eigen build uses for these sizes, including the row-major GEMV
+// kernel Eigen switches to when nx >= 8 and nu >= 8 (WavePlans below; Eigen/src/Core/GeneralProduct.h: gemv_dense_selector).
+// Results are BITWISE identical to the compiled reference.  The loop-carried state lives in the row-layout arrays
+// (row width 64) and is streamed every iteration; the whole wave leaves the iteration loop when its instance converges,
+// so there is no lock-step waste.  fma arithmetic for these sizes is the MFMA streaming kernel (admm_stream.hip).
+#include "rowlane_math.h"
+
+namespace tinympc
+{
+
+enum : int { PLAN_GEMV = 3 };
+
+// Eigen's row-major GEMV inner product (general_matrix_vector_product, RowMajor lhs): four packet lanes accumulated
+// sequentially FROM ZERO, predux (c0+c2)+(c1+c3), scalar leftover, then res = 0 + 1*acc
+template <int NN>
+__device__ __forceinline__ float reduce_gemv(const float (&t)[NN])
+{
+    constexpr int NPK = NN / 4;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPK; k++)
+    {
+        c0 = c0 + t[4 * k + 0]; c1 = c1 + t[4 * k + 1]; c2 = c2 + t[4 * k + 2]; c3 = c3 + t[4 * k + 3];
+    }
+    float res = (c0 + c2) + (c1 + c3);
+#pragma unroll
+    for (int k = 4 * NPK; k < NN; k++) res = res + t[k];
+    return 0.f + res;
+}
+template <int PLAN, int NN>
+__device__ __forceinline__ float wreduce(const float (&t)[NN])
+{
+    if constexpr (PLAN == PLAN_GEMV) return reduce_gemv(t);
+    else return reduce<PLAN>(t);
+}
+
+template <int NX, int NU>
+struct WavePlans
+{
+    static_assert(NX > 1 && NU >= 1 && NX + NU <= 64, "wave kernel needs 1 < nx, nx + nu <= 64");
+    static constexpr bool GEMV = (NU >= 8 && NX >= 8); // product_type_selector<Large,1,Large> = GemvProduct
+    // forward_pass (admm.cpp:31,35)
+    static constexpr int FWD_U = (NU > 1 && NU % 4 == 0) ? PLAN_SEQ : (NU == 1 ? plan_vec(NX) : plan_novec(NX));
+    static constexpr int FWD_XA = (NX % 4 == 0) ? PLAN_SEQ : plan_novec(NX);
+    static constexpr int FWD_XB = (NX % 4 == 0) ? PLAN_SEQ : plan_novec(NU);
+    static constexpr int TERM = plan_vec(NX);                                   // admm.cpp:83
+    // backward_pass_grad (admm.cpp:19-20)
+    static constexpr int BWD_TMP = GEMV ? PLAN_GEMV : plan_vec(NX);
+    static constexpr int BWD_D = GEMV ? PLAN_SEQ : ((NU > 1 && NU % 4 == 0) ? PLAN_SEQ : plan_novec(NU));
+    static constexpr int BWD_PA = (NU == 1 && NX % 4 == 0) ? PLAN_SEQ : plan_novec(NX);
+    static constexpr int BWD_PK = plan_vec(NU);
+};
+
+// t[k] = M[k] * s[K0 + k].  The broadcast goes through LDS: every lane stores its element, then all lanes read the same
+// 16-byte groups (ds_read_b128, broadcast reads are conflict free) and multiply with plain VGPR operands.  LDS
+// operations of one wave execute in order, so no barrier is needed between the store and the loads.  (The alternative,
+// v_readlane_b32 + v_mul_f32 with an SGPR operand, costs two 4-cycle VALU instructions per product: measured 1.2-1.4x slower.)
+template <int K0, int CNT>
+__device__ __forceinline__ void lane_products(float (&t)[CNT], float s, const float (&M)[CNT], float *vec, int lane)
+{
+    vec[lane] = s;
+    if constexpr (K0 % 4 == 0 && CNT % 4 == 0)
+    {
+#pragma unroll
+        for (int k4 = 0; k4 < CNT / 4; k4++)
+        {
+            const float4 v = reinterpret_cast<const float4 *>(vec + K0)[k4];
+            t[4 * k4 + 0] = M[4 * k4 + 0] * v.x; t[4 * k4 + 1] = M[4 * k4 + 1] * v.y;
+            t[4 * k4 + 2] = M[4 * k4 + 2] * v.z; t[4 * k4 + 3] = M[4 * k4 + 3] * v.w;
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int k = 0; k < CNT; k++) t[k] = M[k] * vec[K0 + k];
+    }
+}
+
+template <int NX, int NU>
+struct WaveGains
+{
+    float M1[NX], M2[NU], M3[NX], M45[NU]; // same packing as RowGains (tinympc_batch.hip: pack_gains), row width 64
+    __device__ __forceinline__ void load(const float *mats, int lane)
+    {
+        const float *m = mats + lane;
+#pragma unroll
+        for (int k = 0; k < NX; k++) M1[k] = m[(k) * WAVE];
+#pragma unroll
+        for (int k = 0; k < NU; k++) M2[k] = m[(NX + k) * WAVE];
+#pragma unroll
+        for (int k = 0; k < NX; k++) M3[k] = m[(NX + NU + k) * WAVE];
+#pragma unroll
+        for (int k = 0; k < NU; k++) M45[k] = m[(2 * NX + NU + k) * WAVE];
+    }
+};
+
+// forward_pass step (admm.cpp:31,35)
+template <int NX, int NU>
+__device__ __forceinline__ void wave_lqr_step(const WaveGains<NX, NU> &G, float *vec, int lane, bool is_x, bool is_u, float s, float ci, float &sv, float &xn)
+{
+    using PL = WavePlans<NX, NU>;
+    float t[NX];
+    lane_products<0, NX>(t, s, G.M1, vec, lane);
+    float acc;
+    if constexpr (PL::FWD_U == PL::FWD_XA) acc = wreduce<PL::FWD_XA>(t);
+    else acc = is_x ? wreduce<PL::FWD_XA>(t) : wreduce<PL::FWD_U>(t);
+    const float un = acc - ci; // u rows of M1 hold -Kinf: (-(K x)) - d
+    float t2[NU];
+    lane_products<NX, NU>(t2, un, G.M2, vec, lane);
+    xn = acc + wreduce<PL::FWD_XB>(t2);
+    sv = is_u ? un : s;
+}
+
+// backward_pass_grad step (admm.cpp:19-20)
+template <int NX, int NU>
+__device__ __forceinline__ void wave_riccati_step(const WaveGains<NX, NU> &G, float *vec, int lane, bool is_x, float p, float lin, float &pn, float &dd)
+{
+    using PL = WavePlans<NX, NU>;
+    float t[NX];
+    lane_products<0, NX>(t, p, G.M3, vec, lane);
+    float dot;
+    if constexpr (PL::BWD_PA == PL::BWD_TMP) dot = wreduce<PL::BWD_PA>(t);
+    else dot = is_x ? wreduce<PL::BWD_PA>(t) : wreduce<PL::BWD_TMP>(t);
+    const float wv = lin + dot; // q + AmBKt*p  |  Bdyn^T*p + r
+    float tk[NU], td[NU];
+    lane_products<NX, NU>(tk, lin, G.M45, vec, lane); // Kinf^T * r
+    lane_products<NX, NU>(td, wv, G.M45, vec, lane);  // Quu_inv * (Bdyn^T p + r)
+    pn = wv - wreduce<PL::BWD_PK>(tk);
+    if constexpr (PL::GEMV) dd = 0.f + (0.f + wreduce<PLAN_SEQ>(td)); // 0 + 1*(0 + dot_seq), as the GEMV path leaves it
+    else dd = wreduce<PL::BWD_D>(td);
+}
+
+template <int NX, int NU>
+__global__ __launch_bounds__(WAVE, 3) void admm_wavestream_kernel(const RowParams P)
+{
+    using PL = WavePlans<NX, NU>;
+    __shared__ __attribute__((aligned(16))) float vec[WAVE]; // broadcast buffer of lane_products
+    const int lane = threadIdx.x;
+    const int inst = blockIdx.x;
+    const bool is_x = lane < NX, is_u = (lane >= NX) && (lane < NX + NU);
+    const int N = P.N;
+    const int rowbase = (inst * N) * WAVE + lane;
+    const float rho = P.rho;
+    const float2 *bnd = reinterpret_cast<const float2 *>(P.bounds);
+    WaveGains<NX, NU> G;
+    G.load(P.mats, lane);
+    const float qrow = P.mats[(2 * NX + 2 * NU) * WAVE + lane];
+    int wstart = 0;
+    if (P.xref_mode == 1) wstart = P.xref_start[inst];
+    const int xref_off = inst * (int)P.xref_inst_stride + lane;
+    auto xref_at = [&](int i) {
+        if (P.xref_mode == 1)
+        {
+            int row = wstart + i;
+            row = row < P.table_rows ? row : P.table_rows - 1;
+            return P.xref_table[row * WAVE + lane];
+        }
+        return P.xref[xref_off + i * WAVE];
+    };
+    const float x0 = P.xu[rowbase];
+    float pterm;
+    {
+        // -(Xref_{N-1}^T Pinf) (admm.cpp:83), x rows; PT[k] = Pinf(k, r)
+        float PT[NX], t[NX];
+#pragma unroll
+        for (int k = 0; k < NX; k++) PT[k] = P.mats[(2 * NX + 2 * NU + 1 + k) * WAVE + lane];
+        lane_products<0, NX>(t, xref_at(N - 1), PT, vec, lane);
+        pterm = -wreduce<PL::TERM>(t);
+    }
+    int st = TINY_STATUS_UNSOLVED_, itn = 1;
+    float r_ps = 0.f, r_pi = 0.f, r_ds = 0.f, r_di = 0.f;
+    if (!P.cold_start)
+    {
+        r_ps = P.res[4 * inst + 0]; r_pi = P.res[4 * inst + 1];
+        r_ds = P.res[4 * inst + 2]; r_di = P.res[4 * inst + 3];
+    }
+    // max over the lanes of the wave, every lane gets the result
+    auto wave_max = [](float v) {
+        v = fmaxf(v, dpp_mov<0x128>(v)); v = fmaxf(v, dpp_mov<0x124>(v)); v = fmaxf(v, dpp_mov<0x122>(v)); v = fmaxf(v, dpp_mov<0x121>(v));
+        float m = v; // row maxima -> wave maximum through SGPRs
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)));
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)));
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48)));
+        return fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)));
+    };
+    for (int it = 0; it < P.max_iter; ++it)
+    {
+        const bool last_iter = (it == P.max_iter - 1);
+        const bool zero_state = (it == 0) && (P.cold_start != 0);
+        const bool zero_duals = (it == 0) && ((P.cold_start | P.duals_zero) != 0);
+        float s = x0, pri = 0.f, dua = 0.f, t1 = 0.f;
+        // the streamed state of step i+1 is requested before step i computes: the sweep is a dependent chain and the
+        // compiler cannot hoist loads over the stores of the step (the arrays are distinct, it cannot know)
+        float d_nx = zero_state ? 0.f : P.pd[rowbase], a_nx = zero_duals ? 0.f : P.gy[rowbase], b_nx = zero_state ? 0.f : P.vz[rowbase];
+        float2 lh_nx = bnd[lane];
+        for (int i = 0; i < N; i++)
+        {
+            const int o = rowbase + i * WAVE;
+            const float di = d_nx, a = a_nx, bprev = b_nx;
+            const float2 lh = lh_nx;
+            if (i + 1 < N)
+            {
+                d_nx = zero_state ? 0.f : P.pd[o + WAVE]; a_nx = zero_duals ? 0.f : P.gy[o + WAVE]; b_nx = zero_state ? 0.f : P.vz[o + WAVE];
+                lh_nx = bnd[(i + 1) * WAVE + lane];
+            }
+            float sv, xn = 0.f;
+            if (i < N - 1) wave_lqr_step<NX, NU>(G, vec, lane, is_x, is_u, s, di, sv, xn);
+            else sv = is_x ? s : 0.f;
+            const float t = __builtin_amdgcn_fmed3f(sv + a, lh.x, lh.y); // admm.cpp:47-60 (lo := min(lo, hi) on the host)
+            const float an = (a + sv) - t;                               // admm.cpp:69-70
+            pri = fmaxf(pri, fabsf(sv - t));
+            dua = fmaxf(dua, fabsf(bprev - t));
+            P.vzn[o] = t;
+            P.gy[o] = an;
+            if (last_iter) P.xu[o] = sv;
+            t1 = t - an;
+            s = xn;
+        }
+        const float pN = pterm - rho * t1; // admm.cpp:83-84
+        P.pd[rowbase + (N - 1) * WAVE] = is_x ? pN : 0.f;
+        const float pri_x = wave_max(is_x ? pri : 0.f), dua_x = wave_max(is_x ? dua : 0.f);
+        const float pri_u = wave_max(is_u ? pri : 0.f), dua_u = wave_max(is_u ? dua : 0.f);
+        itn = it + 1;
+        bool conv = false;
+        if ((it + 1) % P.check_termination == 0) // admm.cpp:91-109
+        {
+            r_ps = pri_x; r_ds = dua_x * rho; r_pi = pri_u; r_di = dua_u * rho;
+            conv = (r_ps < P.abs_pri_tol) && (r_pi < P.abs_pri_tol) && (r_ds < P.abs_dua_tol) && (r_di < P.abs_dua_tol);
+        }
+        if (conv) // wave-uniform: the instance is the wave
+        {
+            st = TINY_STATUS_SOLVED_;
+            break;
+        }
+        float p = pN;
+        P.vz[rowbase + (N - 1) * WAVE] = P.vzn[rowbase + (N - 1) * WAVE]; // admm.cpp:141-142
+        float sn_nx = P.vzn[rowbase + (N - 2) * WAVE], g_nx = P.gy[rowbase + (N - 2) * WAVE], xr_nx = xref_at(N - 2);
+        for (int i = N - 2; i >= 0; i--)
+        {
+            const int o = rowbase + i * WAVE;
+            const float sni = sn_nx, gi = g_nx, xri = xr_nx;
+            if (i > 0) { sn_nx = P.vzn[o - WAVE]; g_nx = P.gy[o - WAVE]; xr_nx = xref_at(i - 1); }
+            const float cq = is_x ? -(xri * qrow) : 0.f;
+            float pn, dd;
+            wave_riccati_step<NX, NU>(G, vec, lane, is_x, p, cq - rho * (sni - gi), pn, dd); // admm.cpp:19-20,80-82
+            P.pd[o] = is_u ? dd : pn;
+            P.vz[o] = sni;
+            p = pn;
+        }
+    }
+    if (P.max_iter <= 0) // tiny_solve only sets status and iter (admm.cpp:114-117,151)
+    {
+        if (lane == 0)
+        {
+            P.status[inst] = TINY_STATUS_UNSOLVED_;
+            P.iter[inst] = 1;
+            atomicAdd(P.n_unsolved, 1);
+        }
+        return;
+    }
+    {
+        // live-out: q, r (admm.cpp:80-82) and, for a converged instance, x,u regenerated from the d it converged with
+        const bool solved = (st == TINY_STATUS_SOLVED_);
+        float s = x0;
+        for (int i = 0; i < N; i++)
+        {
+            const int o = rowbase + i * WAVE;
+            float sv, xn = 0.f;
+            if (i < N - 1) wave_lqr_step<NX, NU>(G, vec, lane, is_x, is_u, s, P.pd[o], sv, xn);
+            else sv = is_x ? s : 0.f;
+            if (solved) P.xu[o] = sv;
+            s = xn;
+            const float cq = is_x ? -(xref_at(i) * qrow) : 0.f;
+            const float lin = cq - rho * (P.vzn[o] - P.gy[o]);
+            P.qr[o] = (i < N - 1 || is_x) ? lin : 0.f;
+        }
+        if (lane == 0)
+        {
+            P.res[4 * inst + 0] = r_ps; P.res[4 * inst + 1] = r_pi;
+            P.res[4 * inst + 2] = r_ds; P.res[4 * inst + 3] = r_di;
+            P.status[inst] = st;
+            P.iter[inst] = itn;
+            if (!solved) atomicAdd(P.n_unsolved, 1);
+        }
+    }
+}
+
+bool wavedims_supported(int nx, int nu)
+{
+#define TINY_WAVEDIMS_CHECK(NX, NU) \
+    if (nx == NX && nu == NU) return true;
+    TINY_FOR_EACH_WAVEDIMS(TINY_WAVEDIMS_CHECK)
+    return false;
+}
+
+hipError_t launch_admm_wavestream(int nx, int nu, const RowParams &P, hipStream_t stream)
+{
+#define TINY_WAVE_DISPATCH(NX, NU)                                                                         \
+    if (nx == NX && nu == NU)                                                                              \
+    {                                                                                                      \
+        hipLaunchKernelGGL((admm_wavestream_kernel<NX, NU>), dim3(P.batch), dim3(WAVE), 0, stream, P);    \
+        return hipGetLastError();                                                                          \
+    }
+    TINY_FOR_EACH_WAVEDIMS(TINY_WAVE_DISPATCH)
+    return hipErrorInvalidValue;
+}
+
+} // namespace tinympc

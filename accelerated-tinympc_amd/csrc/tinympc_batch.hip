@@ -57,11 +57,13 @@ enum { VAR_AUTO = 0, VAR_STREAM = 1, VAR_ROW_EXACT = 2, VAR_ROW_FAST = 3 };
 // Element addressing of the two device layouts.  `fam` 0 = state-type (nx rows, N steps),
 // 1 = input-type (nu rows, N-1 steps).
 //   TILE (admm_stream.hip):  x-family [ntiles][N][64][NXC], u-family [ntiles][N-1][64][NUC]
-//   ROW  (admm_rowlane.hip): pair array [batch_pad4][N][16], rows [0,nx) state member, [nx,nx+nu) input member
+//   ROW  (row / wave kernels): pair array [batch_pad4][N][rw], rows [0,nx) state member, [nx,nx+nu) input member;
+//        rw = 16 (one DPP row per instance) or 64 (one wavefront per instance, admm_wave.hip)
 // ---------------------------------------------------------------------------------------------
 struct Geo
 {
     int nx, nu, N, NXC, NUC;
+    int rw; // lanes per instance-step of the ROW layout: 16 (one DPP row) or 64 (one wavefront, 16 < nx + nu <= 64)
 };
 
 __device__ __forceinline__ long long idx_tile(const Geo g, int fam, int b, int step, int row)
@@ -72,7 +74,7 @@ __device__ __forceinline__ long long idx_tile(const Geo g, int fam, int b, int s
 }
 __device__ __forceinline__ long long idx_row(const Geo g, int fam, int b, int step, int row)
 {
-    return ((long long)b * g.N + step) * 16 + (fam ? g.nx + row : row);
+    return ((long long)b * g.N + step) * g.rw + (fam ? g.nx + row : row);
 }
 __device__ __forceinline__ long long idx_of(int layout, const Geo g, int fam, int b, int step, int row)
 {
@@ -190,7 +192,8 @@ struct TinyBatch
 {
     int nx = 0, nu = 0, N = 0, batch = 0, device = 0;
     int NXC = 0, NUC = 0, ntiles = 0, bpad4 = 0;
-    bool row_dims_ok = false, tile_dims_ok = false, rowmath_ok = false, rowloop_ok = false;
+    int rw = 16; // lanes per instance-step of the ROW layout
+    bool row_dims_ok = false, tile_dims_ok = false, rowmath_ok = false, rowloop_ok = false, wave_ok = false;
     int *conv_dev = nullptr; // [batch] result of termination_condition
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr; // created by tiny_batch_group_solve for handles left on the null stream
@@ -237,7 +240,7 @@ struct TinyBatch
 namespace
 {
 
-Geo geo(const TinyBatch *tb) { return Geo{tb->nx, tb->nu, tb->N, tb->NXC, tb->NUC}; }
+Geo geo(const TinyBatch *tb) { return Geo{tb->nx, tb->nu, tb->N, tb->NXC, tb->NUC, tb->rw}; }
 
 int set_device(TinyBatch *tb)
 {
@@ -482,8 +485,9 @@ int pack_gains(TinyBatch *tb)
         TRY(upload_vec(tb, &tb->opnd, o));
         TRY(upload_vec(tb, &tb->qvec, qv));
     }
-    if (tb->rowmath_ok)
+    if (tb->rowmath_ok || tb->wave_ok)
     {
+        const int RW = tb->rw;
         // ---- gains for the rowlane kernel: [3nx + 2nu + 1][16], entry (reg, r) = the value lane r of a row holds.
         //   M1[k]  (k<nx): x rows A(r,k)      | u rows -K(m,k)
         //   M2[m]  (m<nu): x rows B(r,m)      | u rows  0
@@ -495,23 +499,23 @@ int pack_gains(TinyBatch *tb)
         {
             const float sg = fast ? -1.f : 1.f;
             const int nreg = 3 * nx + 2 * nu + 1;
-            std::vector<float> m((size_t)nreg * 16, 0.f);
-            for (int r = 0; r < 16; r++)
+            std::vector<float> m((size_t)nreg * RW, 0.f);
+            for (int r = 0; r < RW; r++)
             {
                 const bool isx = r < nx, isu = r >= nx && r < nx + nu;
                 const int mr = r - nx;
                 for (int k = 0; k < nx; k++)
                 {
-                    m[(size_t)k * 16 + r] = isx ? Aat(r, k) : (isu ? -Kat(mr, k) : 0.f);
-                    m[(size_t)(nx + nu + k) * 16 + r] = isx ? Amat(r, k) : (isu ? Bat(k, mr) : 0.f);
-                    m[(size_t)(2 * nx + 2 * nu + 1 + k) * 16 + r] = isx ? Pat(k, r) : 0.f;
+                    m[(size_t)k * RW + r] = isx ? Aat(r, k) : (isu ? -Kat(mr, k) : 0.f);
+                    m[(size_t)(nx + nu + k) * RW + r] = isx ? Amat(r, k) : (isu ? Bat(k, mr) : 0.f);
+                    m[(size_t)(2 * nx + 2 * nu + 1 + k) * RW + r] = isx ? Pat(k, r) : 0.f;
                 }
                 for (int mm = 0; mm < nu; mm++)
                 {
-                    m[(size_t)(nx + mm) * 16 + r] = isx ? Bat(r, mm) : 0.f;
-                    m[(size_t)(2 * nx + nu + mm) * 16 + r] = isx ? sg * Kat(mm, r) : (isu ? Qiat(mr, mm) : 0.f);
+                    m[(size_t)(nx + mm) * RW + r] = isx ? Bat(r, mm) : 0.f;
+                    m[(size_t)(2 * nx + nu + mm) * RW + r] = isx ? sg * Kat(mm, r) : (isu ? Qiat(mr, mm) : 0.f);
                 }
-                m[(size_t)(2 * nx + 2 * nu) * 16 + r] = isx ? tb->Q[r] : 0.f;
+                m[(size_t)(2 * nx + 2 * nu) * RW + r] = isx ? tb->Q[r] : 0.f;
             }
             TRY(upload_vec(tb, fast ? &tb->mats_fast : &tb->mats_exact, m));
         }
@@ -550,9 +554,10 @@ int prepare_inputs(TinyBatch *tb, int layout)
         // bounds table [N][16]{lo,hi}: +-inf where a bound is disabled or the row carries nothing; lo := min(lo, hi)
         // (min(hi, max(lo, t)) == med3(t, min(lo,hi), hi) for every t, also for the infeasible lo > hi case)
         const float inf = std::numeric_limits<float>::infinity();
-        std::vector<float> tab((size_t)N * 16 * 2);
+        const int RW = tb->rw;
+        std::vector<float> tab((size_t)N * RW * 2);
         for (int i = 0; i < N; i++)
-            for (int r = 0; r < 16; r++)
+            for (int r = 0; r < RW; r++)
             {
                 float lo = -inf, hi = inf;
                 if (r < nx && tb->en_state_bound)
@@ -565,8 +570,8 @@ int prepare_inputs(TinyBatch *tb, int layout)
                     lo = tb->in_bnd[2].set ? tb->in_bnd[2].host[(size_t)i * nu + (r - nx)] : 0.f;
                     hi = tb->in_bnd[3].set ? tb->in_bnd[3].host[(size_t)i * nu + (r - nx)] : 0.f;
                 }
-                tab[((size_t)i * 16 + r) * 2 + 0] = lo < hi ? lo : hi;
-                tab[((size_t)i * 16 + r) * 2 + 1] = hi;
+                tab[((size_t)i * RW + r) * 2 + 0] = lo < hi ? lo : hi;
+                tab[((size_t)i * RW + r) * 2 + 1] = hi;
             }
         if (tb->h16) // same table in binary16 (bounds round to nearest; +-inf stays +-inf); half the floats
         {
@@ -582,7 +587,7 @@ int prepare_inputs(TinyBatch *tb, int layout)
             if (tb->r_bounds) { (void)hipFree(tb->r_bounds); tb->r_bounds = nullptr; }
             TRY(upload_vec(tb, &tb->r_bounds, tab));
         }
-        const size_t nf = (size_t)(tb->in_xref.set && !tb->in_xref.shared ? tb->bpad4 : 1) * N * 16;
+        const size_t nf = (size_t)(tb->in_xref.set && !tb->in_xref.shared ? tb->bpad4 : 1) * N * RW;
         if (tb->r_xref) { (void)hipFree(tb->r_xref); tb->r_xref = nullptr; }
         TRY(dev_alloc_zero(&tb->r_xref, tb->h16 ? (nf + 1) / 2 : nf));
         if (tb->in_xref.set)
@@ -597,11 +602,13 @@ int resolve_variant(TinyBatch *tb, int *out)
 {
     int v = tb->variant;
     // row variants: register-resident kernel when (nx,nu,N) is instantiated, else the any-N row kernel with the state in HBM
-    const bool row_ok = (tb->row_dims_ok || tb->rowmath_ok) && bounds_all_shared(tb);
+    const bool row_ok = (tb->row_dims_ok || tb->rowmath_ok || tb->wave_ok) && bounds_all_shared(tb);
+    if (tb->variant == VAR_ROW_FAST && tb->wave_ok)
+        return fail(TINY_BATCH_EUNSUPPORTED, "the wave-per-instance kernel (16 < nx + nu <= 64) has exact arithmetic only; fma arithmetic for these sizes is the streaming MFMA kernel (variant 1)");
     if (v == VAR_AUTO) v = row_ok ? VAR_ROW_EXACT : VAR_STREAM;
     if ((v == VAR_ROW_EXACT || v == VAR_ROW_FAST) && !row_ok)
     {
-        if (tb->row_dims_ok || tb->rowmath_ok)
+        if (tb->row_dims_ok || tb->rowmath_ok || tb->wave_ok)
             return fail(TINY_BATCH_EUNSUPPORTED, "the row kernels need batch-shared bounds; per-instance bounds run on the streaming kernel");
         return fail(TINY_BATCH_EUNSUPPORTED, "no row kernel instantiation for nx=%d nu=%d (needs nx + nu <= 16)", tb->nx, tb->nu);
     }
@@ -618,6 +625,7 @@ int resolve_variant(TinyBatch *tb, int *out)
 // HBM (rowstream).  tiny_batch_set_row_kernel() can force one of them.
 int row_family(const TinyBatch *tb)
 {
+    if (tb->wave_ok) return 3; // one wavefront per instance, state in HBM (admm_wave.hip)
     if (tb->row_family_forced >= 0) return tb->row_family_forced;
     if (tb->row_dims_ok) return 0;
     if (tb->rowloop_ok) return 1;
@@ -634,6 +642,7 @@ void update_kname(TinyBatch *tb)
     if (v == VAR_STREAM) snprintf(nm, sizeof nm, "stream<%d,%d>", tb->NXC, tb->NUC);
     else if (row_family(tb) == 0) snprintf(nm, sizeof nm, "rowlane<%d,%d,%d,%s%s>", tb->nx, tb->nu, tb->N, ar, sto);
     else if (row_family(tb) == 1) snprintf(nm, sizeof nm, "rowloop<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
+    else if (row_family(tb) == 3) snprintf(nm, sizeof nm, "wavestream<%d,%d,%s>", tb->nx, tb->nu, ar);
     else snprintf(nm, sizeof nm, "rowstream<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
     tb->kname = nm;
 }
@@ -648,7 +657,7 @@ void fill_row_params(TinyBatch *tb, RowParams &P, bool exact)
     P.xref_mode = tb->xref_mode;
     P.xu = tb->pair[0]; P.qr = tb->pair[1]; P.pd = tb->pair[2]; P.vz = tb->pair[3]; P.vzn = tb->pair[4]; P.gy = tb->pair[5];
     P.xref = tb->r_xref;
-    P.xref_inst_stride = (tb->in_xref.set && !tb->in_xref.shared) ? (unsigned)tb->N * 16u : 0u;
+    P.xref_inst_stride = (tb->in_xref.set && !tb->in_xref.shared) ? (unsigned)(tb->N * tb->rw) : 0u;
     P.xref_table = tb->h16 ? tb->tab_row_h : tb->tab_row; P.xref_start = tb->xref_start; P.table_rows = tb->table_rows;
     P.bounds = tb->r_bounds;
     P.mats = exact ? tb->mats_exact : tb->mats_fast;
@@ -741,6 +750,7 @@ int launch_solve(TinyBatch *tb)
         const int fam = row_family(tb);
         e = fam == 0   ? launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
             : fam == 1 ? launch_admm_rowloop(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
+            : fam == 3 ? launch_admm_wavestream(tb->nx, tb->nu, P, tb->stream)
                        : launch_admm_rowstream(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream);
     }
     if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -787,7 +797,8 @@ int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int dev
     // the rowlane kernel addresses its arrays with 32-bit element offsets
     const bool tile_ok = stream_dims_supported(nxc, nuc),
                row_ok = rowlane_supported(nx, nu, N) && ((long long)(batch + 3) * N * 16 < (1ll << 30));
-    if (!tile_ok && !row_ok && !rowdims_supported(nx, nu))
+    const bool wave_ok = !rowdims_supported(nx, nu) && wavedims_supported(nx, nu) && ((long long)(batch + 3) * N * 64 < (1ll << 30));
+    if (!tile_ok && !row_ok && !rowdims_supported(nx, nu) && !wave_ok)
         return fail(TINY_BATCH_EUNSUPPORTED,
                     "no kernel instantiation for nx=%d nu=%d N=%d; add it to TINY_FOR_EACH_DIMS / TINY_FOR_EACH_ROWLANE", nx, nu, N);
     int ndev = 0;
@@ -799,10 +810,12 @@ int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int dev
     tb->tile_dims_ok = tile_ok; tb->row_dims_ok = row_ok;
     tb->rowmath_ok = rowdims_supported(nx, nu) && ((long long)(batch + 3) * N * 16 < (1ll << 30));
     tb->rowloop_ok = tb->rowmath_ok && rowloop_supported(nx, nu, N);
+    tb->wave_ok = wave_ok;
+    tb->rw = wave_ok ? 64 : 16;
     tb->xfam_floats = (size_t)tb->ntiles * N * WAVE * nxc;
     tb->ufam_floats = (size_t)tb->ntiles * (N - 1) * WAVE * nuc;
-    tb->pair_floats = (size_t)tb->bpad4 * N * 16;
-    tb->layout = (row_ok || !tile_ok) ? LAYOUT_ROW : LAYOUT_TILE;
+    tb->pair_floats = (size_t)tb->bpad4 * N * tb->rw;
+    tb->layout = (row_ok || wave_ok || !tile_ok) ? LAYOUT_ROW : LAYOUT_TILE;
     auto cleanup = [&](int rc) { tiny_batch_destroy(tb); return rc; };
     if (hipSetDevice(device) != hipSuccess) return cleanup(fail(TINY_BATCH_EHIP, "hipSetDevice(%d) failed", device));
     if (int rc = alloc_layout(tb, tb->layout)) return cleanup(rc);
@@ -929,14 +942,14 @@ int tiny_batch_set_xref_window(TinyBatch *tb, const float *table, int rows, cons
         if (start[b] < 0 || start[b] + tb->N > rows)
             return fail(TINY_BATCH_EINVAL, "window start[%d]=%d out of range for %d rows, N=%d", b, start[b], rows, tb->N);
     TRY(set_device(tb));
-    // table on the device in both forms: [rows][4 gq][NXC] (streaming kernel) and [rows][16] (rowlane kernel)
-    std::vector<float> tt((size_t)rows * 4 * tb->NXC, 0.f), tr((size_t)rows * 16, 0.f);
+    // table on the device in both forms: [rows][4 gq][NXC] (streaming kernel) and [rows][rw] (row / wave kernels)
+    std::vector<float> tt((size_t)rows * 4 * tb->NXC, 0.f), tr((size_t)rows * tb->rw, 0.f);
     for (int r = 0; r < rows; r++)
         for (int row = 0; row < tb->nx; row++)
         {
             const float v = table[(size_t)r * tb->nx + row];
             tt[((size_t)r * 4 + (row & 3)) * tb->NXC + (row >> 2)] = v;
-            if (row < 16) tr[(size_t)r * 16 + row] = v;
+            if (row < tb->rw) tr[(size_t)r * tb->rw + row] = v;
         }
     if (tb->table_rows != rows)
     {
@@ -948,7 +961,7 @@ int tiny_batch_set_xref_window(TinyBatch *tb, const float *table, int rows, cons
     {
         std::vector<_Float16> th(tr.size());
         for (size_t e = 0; e < tr.size(); e++) th[e] = (_Float16)tr[e];
-        std::vector<float> packed(tr.size() / 2); // rows * 16 halves
+        std::vector<float> packed(tr.size() / 2); // rows * rw halves
         std::memcpy(packed.data(), th.data(), packed.size() * sizeof(float));
         TRY(upload_vec(tb, &tb->tab_row_h, packed));
     }
@@ -1222,7 +1235,7 @@ int tiny_batch_set_storage(TinyBatch *tb, int bits)
     if (bits != 16 && bits != 32) return fail(TINY_BATCH_EINVAL, "storage must be 32 (fp32, default) or 16 (IEEE binary16)");
     const bool want = bits == 16;
     if (want == tb->h16) return 0;
-    if (want && !(tb->row_dims_ok || tb->rowmath_ok))
+    if (want && !(tb->row_dims_ok || tb->rowmath_ok) )
         return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage is implemented by the row kernels only (nx=%d nu=%d has none)", tb->nx, tb->nu);
     if (want && tb->variant == VAR_STREAM) return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage cannot be combined with the streaming kernel");
     TRY(set_device(tb));
@@ -1231,7 +1244,7 @@ int tiny_batch_set_storage(TinyBatch *tb, int bits)
     free_layout(tb, LAYOUT_TILE);
     free_layout(tb, LAYOUT_ROW);
     tb->h16 = want;
-    tb->layout = (want || tb->row_dims_ok || !tb->tile_dims_ok) ? LAYOUT_ROW : LAYOUT_TILE;
+    tb->layout = (want || tb->row_dims_ok || tb->wave_ok || !tb->tile_dims_ok) ? LAYOUT_ROW : LAYOUT_TILE;
     TRY(alloc_layout(tb, tb->layout));
     HIP_TRY(hipMemsetAsync(tb->res, 0, (size_t)tb->batch * 4 * sizeof(float), tb->stream));
     HIP_TRY(hipMemsetAsync(tb->status, 0, (size_t)tb->batch * sizeof(int), tb->stream));

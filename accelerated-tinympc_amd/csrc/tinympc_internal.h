@@ -115,6 +115,11 @@ hipError_t launch_admm_step(int nx, int nu, bool exact, bool h16, int fn, const 
 bool rowloop_supported(int nx, int nu, int N);
 hipError_t launch_admm_rowloop(int nx, int nu, bool exact, bool h16, const RowParams &P, hipStream_t stream);
 
+// wave-per-instance exact kernel (admm_wave.hip): 16 < nx + nu <= 64, any N, state in HBM, row width 64
+#define TINY_FOR_EACH_WAVEDIMS(X) X(32, 16)
+bool wavedims_supported(int nx, int nu);
+hipError_t launch_admm_wavestream(int nx, int nu, const RowParams &P, hipStream_t stream);
+
 hipError_t launch_admm_stream(int nxc, int nuc, const SolveParams &P, hipStream_t stream);
 
 } // namespace tinympc

@@ -161,9 +161,10 @@ extern "C"
     /* Name of the kernel variant the next solve will launch ("rowlane<12,4,30,exact>", "rowstream<12,4,fast>",
      * "stream<3,1>", with ",h16" appended under fp16 storage). */
     const char *tiny_batch_kernel_name(TinyBatch *tb);
-    /* Force a kernel variant: 0 = auto (row kernels in exact arithmetic when the class has one and the bounds are
-     * batch-shared, else streaming), 1 = streaming MFMA kernel (state in HBM, fma arithmetic), 2 = row kernels, exact
-     * arithmetic (bitwise equal to the reference's SSE2 build), 3 = row kernels, fma arithmetic. */
+    /* Force a kernel variant: 0 = auto (exact arithmetic when the class has an exact kernel — nx + nu <= 16: row
+     * kernels, 16 < nx + nu <= 64: wave-per-instance kernel — and the bounds are batch-shared, else streaming),
+     * 1 = streaming MFMA kernel (state in HBM, fma arithmetic), 2 = exact arithmetic (bitwise equal to the reference's
+     * SSE2 build), 3 = row kernels with fma arithmetic (nx + nu <= 16). */
     int tiny_batch_select_kernel(TinyBatch *tb, int variant);
     /* Which row kernel variants 2/3 (and auto) launch: 0 = auto (1 where (nx,nu,N) has an unrolled instantiation, else 2 for
      * N <= 32, else 3), 1 = rowlane (unrolled, state in registers/LDS), 2 = rowloop (rolled loops, state in registers/LDS,
