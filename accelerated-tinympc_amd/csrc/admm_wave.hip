@@ -44,6 +44,7 @@ template <int NX, int NU>
 struct WavePlans
 {
     static_assert(NX > 1 && NU >= 1 && NX + NU <= 64, "wave kernel needs 1 < nx, nx + nu <= 64");
+    static_assert((NX <= 4 || NX % 4 == 0) && (NU <= 4 || NU % 4 == 0), "exact arithmetic is defined for nx, nu <= 4 or multiples of 4 (rowlane_math.h)");
     static constexpr bool GEMV = (NU >= 8 && NX >= 8); // product_type_selector<Large,1,Large> = GemvProduct
     // forward_pass (admm.cpp:31,35)
     static constexpr int FWD_U = (NU > 1 && NU % 4 == 0) ? PLAN_SEQ : (NU == 1 ? plan_vec(NX) : plan_novec(NX));

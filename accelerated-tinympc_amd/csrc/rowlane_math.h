@@ -148,6 +148,9 @@ struct RowPlans
 {
     static_assert(NX > 1 && NU >= 1 && NX + NU <= 16, "rowlane kernel needs 1 < nx, nx + nu <= 16");
     static_assert(!(NU >= 8 && NX >= 8), "Eigen switches to its GEMV kernel there; not restated");
+    // For a result with rows > 4 and rows % 4 != 0 the reference's order depends on the 16-byte alignment of each
+    // destination column (Eigen LinearVectorized assignment; measured for nu = 7): no bitwise claim is possible there.
+    static_assert((NX <= 4 || NX % 4 == 0) && (NU <= 4 || NU % 4 == 0), "exact arithmetic is defined for nx, nu <= 4 or multiples of 4");
     // forward_pass (admm.cpp:31,35)
     static constexpr int FWD_U = (NU > 1 && NU % 4 == 0) ? PLAN_SEQ : (NU == 1 ? plan_vec(NX) : plan_novec(NX));
     static constexpr int FWD_XA = (NX % 4 == 0) ? PLAN_SEQ : plan_novec(NX);

@@ -164,6 +164,12 @@ class Oracle(_Solver):
 
     def __init__(self, prob, dtype=np.float32, settings=None):
         super().__init__(prob, dtype, settings)
+        ps = 2 if self.T.suf == "f64" else 4
+        for name, rows in (("nx", self.nx), ("nu", self.nu)):
+            if rows > ps and rows % ps:
+                raise ValueError(f"{name}={rows}: the reference's summation order for results with rows >= {ps} and rows % {ps} != 0 "
+                                 "depends on the 16-byte alignment of each destination column (Eigen LinearVectorized "
+                                 "assignment) and is not restated; see the header of tinympc_oracle_impl.h")
         self.lib = _lib()
         self.PS = _problem_struct(self.T)
         self.BS = _batch_struct(self.T)

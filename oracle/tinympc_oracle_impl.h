@@ -137,7 +137,12 @@ static REAL SUF(dot_gemv_rm)(const REAL *a, const REAL *b, int n)
 }
 
 /* (row i of a column-major rows x cols matrix) . xin, for a lazy product whose result has `rows`
- * rows: packet-evaluated (seq) when rows is a multiple of PS, else coefficient-wise (novec). */
+ * rows: packet-evaluated (seq) when rows is a multiple of PS, else coefficient-wise (novec).
+ * NOT RESTATED: rows > PS with rows % PS != 0 (e.g. nu = 7 in fp32).  There Eigen's LinearVectorized assignment
+ * packet-evaluates (seq) only a window of rows starting at the first 16-byte aligned element of the destination column
+ * and coefficient-evaluates (novec) the rest, so the order of u.col(i) depends on i mod PS and on the offset of the
+ * member inside TinyWorkspace (measured against the compiled reference for nx = 20, nu = 7).  oracle.py refuses such
+ * dimensions; every configuration of the reference's examples and of BASELINE.json has nx, nu in {1, 3, 4, 8, 12, 16, 32}. */
 static inline REAL SUF(row_dot)(const REAL *M, int rows, int cols, int i, const REAL *xin)
 {
     if (rows > 1 && rows % PS == 0) return SUF(dot_seq)(M + i, rows, xin, cols);

@@ -130,3 +130,16 @@ def test_fp16_storage_oracle_rounding_and_fixpoint(oracle_mod):
     for k in O.STATE_ORDER:
         assert np.array_equal(st[k], st2[k])
     assert np.all(st2["status"] == 11) and np.all(st2["iter"] == 1)
+
+
+def test_oracle_refuses_dims_whose_reference_result_depends_on_alignment(oracle_mod, tinympc):
+    """For a result with rows >= packet size and rows % packet size != 0 (e.g. nu = 7 in fp32) Eigen's LinearVectorized
+    assignment packet-evaluates a window of rows that starts at the first 16-byte aligned element of the destination
+    COLUMN, so the summation order of u.col(i) changes with i mod 4 (measured against the compiled reference for
+    nx = 20, nu = 7: rows [0,4) packet/sequential at i = 0, [1,5) at i = 1, ...).  The restatement does not model
+    that and must say so instead of returning almost-right numbers."""
+    O = oracle_mod
+    prob = tinympc.problems.random_system(20, 7, 9, seed=1)
+    with pytest.raises(ValueError):
+        O.Oracle(prob, np.float32)
+    O.Oracle(tinympc.problems.random_system(8, 3, 7, seed=1), np.float32)  # nu < packet size: fine
