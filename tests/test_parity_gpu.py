@@ -870,3 +870,40 @@ def test_device_pointer_io_equals_host_io(tinympc):
     for p in (d_xref, d_x, d_u):
         hip.hipFree(p)
     sol.close(); ref.close()
+
+
+@pytest.mark.parametrize("B", [1, 3, 66])
+def test_wave_kernel_vs_oracle(tinympc, oracle_mod, B):
+    """nx = 32, nu = 16, N = 50 (BASELINE.json configs[3]) on the wave-per-instance exact kernel: bitwise equal to the
+    oracle (== the compiled reference for this class, tests/test_oracle.py) over a warm-started chain, with early exit,
+    sparse termination checks, one iteration, bounds disabled and a random time-varying reference."""
+    O, pr = oracle_mod, tinympc.problems
+    prob = pr.random_system(32, 16, 50)
+    nx, nu, N = 32, 16, 50
+    rng = np.random.default_rng(B)
+    x0 = rng.uniform(-1, 1, size=(B, nx)).astype(np.float32)
+    xref = (rng.standard_normal((B, N, nx)) * 0.2).astype(np.float32)
+    bnds = pr.bounds_arrays(prob)
+    for settings in (dict(max_iter=40), dict(max_iter=25, check_termination=4), dict(max_iter=1),
+                     dict(max_iter=12, en_state_bound=0, en_input_bound=0), dict(max_iter=0)):
+        settings = dict(O.DEFAULT_SETTINGS, **settings)
+        sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+        assert sol.kernel_name() == "wavestream<32,16,exact>", sol.kernel_name()
+        sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
+        orc = O.Oracle(prob, np.float32, settings)
+        st = O.new_state(B, nx, nu, N); st["x"][:, 0] = x0
+        for k in range(3):
+            st["y"][:] = 0; st["g"][:] = 0
+            sol.reset_dual_variables()
+            rc_ref = orc.solve(st, *bnds, xref, nthreads=8)
+            rc = sol.solve()
+            assert rc == (1 if rc_ref else 0)
+            assert_bitwise(sol.get_state(), st, f"wave B={B} {settings} k={k}")
+        with pytest.raises(tinympc.TinyBatchError):
+            sol.select_kernel(3)      # fma arithmetic for this class is the streaming kernel
+        sol.select_kernel(1)          # ... which takes over the same workspace
+        assert sol.kernel_name() == "stream<8,4>"
+        got = sol.get_state()
+        for name in STATE_ORDER:
+            assert np.array_equal(got[name], st[name]), f"layout switch lost {name}"
+        sol.close()
