@@ -193,7 +193,7 @@ struct TinyBatch
     int nx = 0, nu = 0, N = 0, batch = 0, device = 0;
     int NXC = 0, NUC = 0, ntiles = 0, bpad4 = 0;
     int rw = 16; // lanes per instance-step of the ROW layout
-    bool row_dims_ok = false, tile_dims_ok = false, rowmath_ok = false, rowloop_ok = false, wave_ok = false;
+    bool row_dims_ok = false, tile_dims_ok = false, rowmath_ok = false, rowloop_ok = false, wave_ok = false, quad_ok = false;
     int *conv_dev = nullptr; // [batch] result of termination_condition
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr; // created by tiny_batch_group_solve for handles left on the null stream
@@ -627,6 +627,7 @@ int row_family(const TinyBatch *tb)
 {
     if (tb->wave_ok) return 3; // one wavefront per instance, state in HBM (admm_wave.hip)
     if (tb->row_family_forced >= 0) return tb->row_family_forced;
+    if (tb->quad_ok) return 4; // four lanes per instance (admm_quadlane.hip): nx = 4, nu = 1
     if (tb->row_dims_ok) return 0;
     if (tb->rowloop_ok) return 1;
     return 2;
@@ -643,6 +644,7 @@ void update_kname(TinyBatch *tb)
     else if (row_family(tb) == 0) snprintf(nm, sizeof nm, "rowlane<%d,%d,%d,%s%s>", tb->nx, tb->nu, tb->N, ar, sto);
     else if (row_family(tb) == 1) snprintf(nm, sizeof nm, "rowloop<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
     else if (row_family(tb) == 3) snprintf(nm, sizeof nm, "wavestream<%d,%d,%s>", tb->nx, tb->nu, ar);
+    else if (row_family(tb) == 4) snprintf(nm, sizeof nm, "quadlane<%d,%d,%d,%s%s>", tb->nx, tb->nu, tb->N, ar, sto);
     else snprintf(nm, sizeof nm, "rowstream<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
     tb->kname = nm;
 }
@@ -751,6 +753,7 @@ int launch_solve(TinyBatch *tb)
         e = fam == 0   ? launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
             : fam == 1 ? launch_admm_rowloop(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
             : fam == 3 ? launch_admm_wavestream(tb->nx, tb->nu, P, tb->stream)
+            : fam == 4 ? launch_admm_quadlane(tb->N, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
                        : launch_admm_rowstream(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream);
     }
     if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -811,6 +814,7 @@ int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int dev
     tb->rowmath_ok = rowdims_supported(nx, nu) && ((long long)(batch + 3) * N * 16 < (1ll << 30));
     tb->rowloop_ok = tb->rowmath_ok && rowloop_supported(nx, nu, N);
     tb->wave_ok = wave_ok;
+    tb->quad_ok = tb->rowmath_ok && quadlane_supported(nx, nu, N);
     tb->rw = wave_ok ? 64 : 16;
     tb->xfam_floats = (size_t)tb->ntiles * N * WAVE * nxc;
     tb->ufam_floats = (size_t)tb->ntiles * (N - 1) * WAVE * nuc;
@@ -1221,11 +1225,14 @@ const char *tiny_batch_kernel_name(TinyBatch *tb)
 int tiny_batch_set_row_kernel(TinyBatch *tb, int family)
 {
     CHECK_TB(tb);
-    if (family < 0 || family > 3) return fail(TINY_BATCH_EINVAL, "row kernel must be 0 (auto), 1 (rowlane), 2 (rowloop) or 3 (rowstream)");
-    const bool ok = family == 0 || (family == 1 && tb->row_dims_ok) || (family == 2 && tb->rowloop_ok) || (family == 3 && tb->rowmath_ok);
+    if (family < 0 || family > 4)
+        return fail(TINY_BATCH_EINVAL, "row kernel must be 0 (auto), 1 (rowlane), 2 (rowloop), 3 (rowstream) or 4 (quadlane)");
+    const bool ok = family == 0 || (family == 1 && tb->row_dims_ok) || (family == 2 && tb->rowloop_ok) || (family == 3 && tb->rowmath_ok) ||
+                    (family == 4 && tb->quad_ok);
     if (!ok)
         return fail(TINY_BATCH_EUNSUPPORTED, "row kernel %d has no instantiation for nx=%d nu=%d N=%d", family, tb->nx, tb->nu, tb->N);
-    tb->row_family_forced = family - 1;
+    static const int kFam[5] = {-1, 0, 1, 2, 4};
+    tb->row_family_forced = kFam[family];
     return 0;
 }
 

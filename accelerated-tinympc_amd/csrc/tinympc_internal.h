@@ -115,6 +115,10 @@ hipError_t launch_admm_step(int nx, int nu, bool exact, bool h16, int fn, const 
 bool rowloop_supported(int nx, int nu, int N);
 hipError_t launch_admm_rowloop(int nx, int nu, bool exact, bool h16, const RowParams &P, hipStream_t stream);
 
+// four-lanes-per-instance register-resident kernel (admm_quadlane.hip): nx = 4, nu = 1, instantiated horizons only
+bool quadlane_supported(int nx, int nu, int N);
+hipError_t launch_admm_quadlane(int N, bool exact, bool h16, const RowParams &P, hipStream_t stream);
+
 // wave-per-instance exact kernel (admm_wave.hip): 16 < nx + nu <= 64, any N, state in HBM, row width 64
 #define TINY_FOR_EACH_WAVEDIMS(X) X(32, 16)
 bool wavedims_supported(int nx, int nu);

@@ -305,7 +305,7 @@ class TinyBatchSolver:
         self._check(self.lib.tiny_batch_select_kernel(self._h, variant))
 
     def set_row_kernel(self, family: int):
-        """0 auto, 1 rowlane (unrolled), 2 rowloop (rolled, N <= 32), 3 rowstream (state in HBM)."""
+        """0 auto, 1 rowlane (unrolled), 2 rowloop (rolled, N <= 32), 3 rowstream (state in HBM), 4 quadlane (nx=4, nu=1)."""
         self._check(self.lib.tiny_batch_set_row_kernel(self._h, family))
 
     def set_storage(self, bits: int):

@@ -166,9 +166,10 @@ extern "C"
      * 1 = streaming MFMA kernel (state in HBM, fma arithmetic), 2 = exact arithmetic (bitwise equal to the reference's
      * SSE2 build), 3 = row kernels with fma arithmetic (nx + nu <= 16). */
     int tiny_batch_select_kernel(TinyBatch *tb, int variant);
-    /* Which row kernel variants 2/3 (and auto) launch: 0 = auto (1 where (nx,nu,N) has an unrolled instantiation, else 2 for
-     * N <= 32, else 3), 1 = rowlane (unrolled, state in registers/LDS), 2 = rowloop (rolled loops, state in registers/LDS,
-     * any N <= 32), 3 = rowstream (any N, state in HBM).  All three compute identical results. */
+    /* Which row kernel variants 2/3 (and auto) launch: 0 = auto (4 where it exists, else 1 where (nx,nu,N) has an unrolled
+     * instantiation, else 2 for N <= 32, else 3), 1 = rowlane (16 lanes per instance, unrolled, state in registers/LDS),
+     * 2 = rowloop (rolled loops, state in registers/LDS, any N <= 32), 3 = rowstream (any N, state in HBM),
+     * 4 = quadlane (4 lanes per instance, nx = 4 and nu = 1 only).  All of them compute identical results. */
     int tiny_batch_set_row_kernel(TinyBatch *tb, int family);
     /* Storage precision of the per-instance horizon arrays (the twelve work arrays, Xref, bounds) in HBM:
      * 32 = fp32 like the reference (default); 16 = IEEE binary16 storage with fp32 arithmetic (BASELINE.json
