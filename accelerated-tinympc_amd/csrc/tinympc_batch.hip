@@ -196,7 +196,9 @@ struct TinyBatch
     bool row_dims_ok = false, tile_dims_ok = false, rowmath_ok = false, rowloop_ok = false, wave_ok = false, quad_ok = false;
     int *conv_dev = nullptr; // [batch] result of termination_condition
     hipStream_t stream = nullptr;
-    hipStream_t own_stream = nullptr; // created by tiny_batch_group_solve for handles left on the null stream
+    hipStream_t own_stream = nullptr; // created by tiny_batch_group_solve / mpc_run for handles left on the null stream
+    hipGraphExec_t graph_exec = nullptr; // tiny_batch_mpc_run_async: captured (solve + plant) x steps
+    std::string graph_sig;
     // problem class
     bool have_cache = false, have_dyn = false, have_settings = false, gains_dirty = true;
     float rho = 0.f;
@@ -252,6 +254,9 @@ int dev_alloc_zero(float **p, size_t nfloats)
 {
     HIP_TRY(hipMalloc((void **)p, nfloats * sizeof(float)));
     HIP_TRY(hipMemset(*p, 0, nfloats * sizeof(float)));
+    // hipMemset of device memory is enqueued on the null stream and may return early; a handle on a non-blocking
+    // stream would not be ordered behind it
+    HIP_TRY(hipStreamSynchronize(nullptr));
     return 0;
 }
 
@@ -698,7 +703,8 @@ int run_step(TinyBatch *tb, int fn, int *converged_host, int *n_true)
     return 0;
 }
 
-int launch_solve(TinyBatch *tb)
+// everything a solve needs that may allocate, copy or synchronise (not capturable in a hipGraph)
+int prepare_solve(TinyBatch *tb, int *variant)
 {
     if (!tb->have_cache || !tb->have_dyn || !tb->have_settings)
         return fail(TINY_BATCH_ENOTREADY, "tiny_batch_solve: set_cache, set_dynamics and set_settings must be called first");
@@ -713,13 +719,23 @@ int launch_solve(TinyBatch *tb)
     int v = 0;
     TRY(resolve_variant(tb, &v));
     if (tb->gains_dirty) TRY(pack_gains(tb));
-    const int layout = (v == VAR_STREAM) ? LAYOUT_TILE : LAYOUT_ROW;
-    TRY(ensure_layout(tb, layout));
-    TRY(prepare_inputs(tb, layout));
+    {
+        const int layout = (v == VAR_STREAM) ? LAYOUT_TILE : LAYOUT_ROW;
+        TRY(ensure_layout(tb, layout));
+        TRY(prepare_inputs(tb, layout));
+    }
     if (tb->max_iter <= 0) TRY(flush_pending(tb));
     update_kname(tb);
+    *variant = v;
+    return 0;
+}
+
+// the stream operations of one solve: counter reset + kernel launch (capturable)
+int enqueue_solve(TinyBatch *tb, int v, bool record_events)
+{
+    const int layout = (v == VAR_STREAM) ? LAYOUT_TILE : LAYOUT_ROW;
     HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, sizeof(int), tb->stream));
-    if (tb->timing) HIP_TRY(hipEventRecord(tb->ev0, tb->stream));
+    if (record_events) HIP_TRY(hipEventRecord(tb->ev0, tb->stream));
     hipError_t e;
     if (layout == LAYOUT_TILE)
     {
@@ -757,12 +773,29 @@ int launch_solve(TinyBatch *tb)
                        : launch_admm_rowstream(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream);
     }
     if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
-    if (tb->timing)
+    if (record_events)
     {
         HIP_TRY(hipEventRecord(tb->ev1, tb->stream));
         tb->ev_valid = true;
     }
     if (tb->max_iter > 0) tb->duals_zero_pending = tb->cold_pending = false; // consumed by the kernel's first iteration
+    return 0;
+}
+
+int launch_solve(TinyBatch *tb)
+{
+    int v = 0;
+    TRY(prepare_solve(tb, &v));
+    return enqueue_solve(tb, v, tb->timing);
+}
+
+int enqueue_plant_step(TinyBatch *tb, int window_advance)
+{
+    hipLaunchKernelGGL(plant_step_kernel, dim3((tb->batch + 127) / 128), dim3(128), 0, tb->stream, tb->x0buf,
+                       work_ptr(tb, TINY_ARR_X), work_ptr(tb, TINY_ARR_U), tb->dA, tb->dB,
+                       tb->xref_mode == 1 ? tb->xref_start : nullptr, window_advance, tb->batch, tb->layout, geo(tb),
+                       h16_of(tb, tb->layout));
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -851,6 +884,7 @@ void tiny_batch_destroy(TinyBatch *tb)
     (void)hipFree(tb->res); (void)hipFree(tb->status); (void)hipFree(tb->iter); (void)hipFree(tb->n_unsolved);
     (void)hipFree(tb->opnd); (void)hipFree(tb->qvec); (void)hipFree(tb->mats_exact); (void)hipFree(tb->mats_fast);
     (void)hipFree(tb->dA); (void)hipFree(tb->dB); (void)hipFree(tb->x0buf); (void)hipFree(tb->staging); (void)hipFree(tb->conv_dev);
+    if (tb->graph_exec) (void)hipGraphExecDestroy(tb->graph_exec);
     if (tb->own_stream) (void)hipStreamDestroy(tb->own_stream);
     if (tb->ev0) (void)hipEventDestroy(tb->ev0);
     if (tb->ev1) (void)hipEventDestroy(tb->ev1);
@@ -1180,11 +1214,57 @@ int tiny_batch_mpc_step_async(TinyBatch *tb, int window_advance)
     // x.col(0) already holds x0 (set_x0 / previous plant step); reset duals, solve, then simulate forward.
     tb->duals_zero_pending = true;
     TRY(tiny_batch_solve_async(tb));
-    hipLaunchKernelGGL(plant_step_kernel, dim3((tb->batch + 127) / 128), dim3(128), 0, tb->stream, tb->x0buf,
-                       work_ptr(tb, TINY_ARR_X), work_ptr(tb, TINY_ARR_U), tb->dA, tb->dB,
-                       tb->xref_mode == 1 ? tb->xref_start : nullptr, window_advance, tb->batch, tb->layout, geo(tb),
-                       h16_of(tb, tb->layout));
-    HIP_TRY(hipGetLastError());
+    return enqueue_plant_step(tb, window_advance);
+}
+
+// `steps` closed-loop MPC steps back to back.  The launch sequence (counter reset, solve kernel, plant kernel) x steps is
+// captured ONCE into a hipGraph and replayed: for small batches and warm-started solves of a few iterations the
+// per-launch overhead is a large part of a step.
+int tiny_batch_mpc_run_async(TinyBatch *tb, int steps, int window_advance)
+{
+    CHECK_TB(tb);
+    if (steps < 1) return fail(TINY_BATCH_EINVAL, "tiny_batch_mpc_run_async: steps must be >= 1");
+    if (tb->nx > 64) return fail(TINY_BATCH_EUNSUPPORTED, "mpc_run supports nx <= 64");
+    if (tb->max_iter <= 0) return fail(TINY_BATCH_EINVAL, "tiny_batch_mpc_run_async needs max_iter > 0");
+    TRY(set_device(tb));
+    if (!tb->stream) // stream capture is not allowed on the null stream
+    {
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        if (!tb->own_stream) HIP_TRY(hipStreamCreateWithFlags(&tb->own_stream, hipStreamNonBlocking));
+        tb->stream = tb->own_stream;
+    }
+    TRY(flush_pending(tb)); // the captured solves all start from "duals reset, workspace warm"
+    tb->duals_zero_pending = true;
+    int v = 0;
+    TRY(prepare_solve(tb, &v));
+    // the graph bakes in kernel arguments: rebuild it whenever anything they depend on may have changed
+    char sig[256];
+    snprintf(sig, sizeof sig, "%d|%d|%d|%s|%d|%d|%g|%g|%d|%d|%p|%p|%p|%d|%p", steps, window_advance, v, tb->kname.c_str(), tb->max_iter,
+             tb->check_termination, (double)tb->abs_pri_tol, (double)tb->abs_dua_tol, tb->xref_mode, tb->table_rows, (void *)tb->pair[0],
+             (void *)tb->arr[0], (void *)tb->r_bounds, (int)tb->h16, (void *)tb->stream);
+    if (!tb->graph_exec || tb->graph_sig != sig)
+    {
+        if (tb->graph_exec) { (void)hipGraphExecDestroy(tb->graph_exec); tb->graph_exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(tb->stream, hipStreamCaptureModeThreadLocal));
+        int rc = 0;
+        for (int k = 0; k < steps && rc == 0; k++)
+        {
+            tb->duals_zero_pending = true;
+            rc = enqueue_solve(tb, v, false);
+            if (rc == 0) rc = enqueue_plant_step(tb, window_advance);
+        }
+        hipError_t ec = hipStreamEndCapture(tb->stream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        HIP_TRY(ec);
+        hipError_t ei = hipGraphInstantiate(&tb->graph_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HIP_TRY(ei);
+        tb->graph_sig = sig;
+    }
+    HIP_TRY(hipGraphLaunch(tb->graph_exec, tb->stream));
+    tb->duals_zero_pending = tb->cold_pending = false;
+    tb->ev_valid = false;
     return 0;
 }
 

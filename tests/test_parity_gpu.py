@@ -909,3 +909,36 @@ def test_wave_kernel_vs_oracle(tinympc, oracle_mod, B):
         for name in STATE_ORDER:
             assert np.array_equal(got[name], st[name]), f"layout switch lost {name}"
         sol.close()
+
+
+@pytest.mark.parametrize("variant_name", ["row_exact", "stream"])
+def test_graph_captured_mpc_run_equals_step_by_step(tinympc, variant_name):
+    """tiny_batch_mpc_run_async(steps) — the (solve + plant step) x steps sequence captured once into a hipGraph and
+    replayed — leaves exactly the state that `steps` calls of tiny_batch_mpc_step_async leave; a second replay of the
+    same graph continues the trajectory, and a change of settings rebuilds the graph."""
+    pr = tinympc.problems
+    prob = pr.quadrotor(20, 30)
+    B = 48
+    x0, table, start = pr.tracking_batch(B, 30, seed=11)
+    bnds = pr.bounds_arrays(prob)
+    a = make_solver(tinympc, prob, B, None, None, variant_name, bnds)
+    b = make_solver(tinympc, prob, B, None, None, variant_name, bnds)
+    for s in (a, b):
+        s.set_xref_window(table, start)
+        s.set_x0(x0)
+    for rounds in range(2):
+        a.mpc_run_async(6, 1)
+        for _ in range(6):
+            b.mpc_step_async(1)
+        sa, sb = a.get_state(), b.get_state()
+        for k in STATE_ORDER + SCALARS:
+            assert np.array_equal(sa[k], sb[k]), f"round {rounds}: {k}"
+        assert np.array_equal(a.get_x0(), b.get_x0())
+    for s in (a, b):
+        s.set_settings(**dict(s.settings, max_iter=7))   # baked into the captured kernel arguments: the graph must be rebuilt
+    a.mpc_run_async(3, 0)
+    for _ in range(3):
+        b.mpc_step_async(0)
+    assert np.array_equal(a.get_u(), b.get_u()) and np.array_equal(a.get_status()[0], b.get_status()[0])
+    assert a.get_status()[0].max() <= 7
+    a.close(); b.close()
