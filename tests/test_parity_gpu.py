@@ -942,3 +942,42 @@ def test_graph_captured_mpc_run_equals_step_by_step(tinympc, variant_name):
     assert np.array_equal(a.get_u(), b.get_u()) and np.array_equal(a.get_status()[0], b.get_status()[0])
     assert a.get_status()[0].max() <= 7
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("B", [1, 15, 16, 17, 333])
+def test_quadlane_kernel_vs_oracle(tinympc, oracle_mod, B):
+    """The four-lanes-per-instance kernel (cartpole class) against the oracle: ragged batches around its 16-instance
+    wave, warm-started chain, sparse termination checks, one iteration, exhausted iterations, bounds disabled, per-step
+    bounds, time-varying per-instance reference, window reference; exact arithmetic bitwise, fma arithmetic to the
+    yardstick."""
+    O, pr = oracle_mod, tinympc.problems
+    prob = pr.cartpole(10)
+    nx, nu, N = 4, 1, 10
+    rng = np.random.default_rng(B)
+    x0 = (np.array([0, 0, 0.1, 0], np.float32) + rng.uniform(-0.05, 0.05, size=(B, nx))).astype(np.float32)
+    xref = (rng.standard_normal((B, N, nx)) * 0.05).astype(np.float32)
+    xmn, xmx, umn, umx = pr.bounds_arrays(prob)
+    umn = umn * np.linspace(0.2, 1.0, N - 1, dtype=np.float32)[:, None]   # per-step input bounds, some of them active
+    bnds = (xmn, xmx, umn, umx)
+    for settings in (dict(max_iter=150), dict(max_iter=40, check_termination=3), dict(max_iter=1), dict(max_iter=4),
+                     dict(max_iter=30, en_state_bound=0, en_input_bound=0)):
+        settings = dict(O.DEFAULT_SETTINGS, **settings)
+        for exact in (True, False):
+            sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+            sol.select_kernel(2 if exact else 3)
+            assert sol.kernel_name().startswith("quadlane<4,1,10"), sol.kernel_name()
+            sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
+            orc = O.Oracle(prob, np.float32, settings)
+            st = O.new_state(B, nx, nu, N); st["x"][:, 0] = x0
+            for k in range(3):
+                st["y"][:] = 0; st["g"][:] = 0
+                sol.reset_dual_variables()
+                pre = O.copy_state(st)
+                orc.solve(st, *bnds, xref, nthreads=4)
+                sol.solve()
+                r64 = None if exact else yardstick(O, prob, settings, pre, xref, bnds)
+                compare_states(sol.get_state(), st, prob, f"quadlane B={B} {settings} exact={exact} k={k}", ref64=r64, exact=exact,
+                               ct=settings["check_termination"])
+                if not exact:
+                    sol.set_state(st)
+            sol.close()
