@@ -1,7 +1,7 @@
 // admm_rowlane.hip — state-on-chip batched TinyMPC ADMM kernel for small problems (nx + nu <= 16).
 //
 // Restates tiny_solve() (src/tinympc/admm.cpp:111-152) with the WHOLE loop-carried state of an instance kept on chip for
-// the entire solve (two VGPRs and two LDS words per horizon step and lane, see below): HBM is touched only to read the
+// the entire solve (three VGPRs and two LDS words per horizon step and lane, see below): HBM is touched only to read the
 // live-in arrays once and to write the live-out arrays once.
 //
 // Mapping ("row lanes"): a DPP row = 16 lanes = ONE instance, 4 instances per wavefront, one wavefront per workgroup.
@@ -58,9 +58,8 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
     //   c[i]  : -(Xref_i.*Q) | d_i                    reference cost term | feed-forward   (VGPR)
     //   b[i]  : v_i          | z_i                    previous slack                       (LDS)
     //   sn[i] : vnew_i       | znew_i                 current slack                        (LDS)
-    // p_i (live-out only) is written to the pd array by every backward sweep together with d_i; the repeated
-    // overwrites of the same lines are absorbed by L2, only the last version reaches HBM.
-    float a[N], c[N];
+    //   pd[i] : p_i          | d_i of the last executed backward sweep (live-out only; live-in until then)   (VGPR)
+    float a[N], c[N], pd[N];
     // 32-bit element offset: lets the compiler address every array as SGPR base + one shared VGPR offset instead of
     // keeping a 64-bit address pair per array alive through the loop (the host checks batch*N*16 < 2^30)
     const int rowbase = (inst * N) * 16 + r16;
@@ -84,8 +83,8 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             }
             else
                 xr = ldw<H16>(P.xref, xref_off + i * 16);
-            const float pd = cold ? 0.f : ldw<H16>(P.pd, rowbase + i * 16);
-            c[i] = is_x ? rnd<H16>(-(xr * qrow)) : pd;       // admm.cpp:81  q(i,j) = -(Xref(i,j) * Q(i))
+            pd[i] = cold ? 0.f : ldw<H16>(P.pd, rowbase + i * 16); // live-in [p_i ; d_i]: kept by an instance that runs no backward sweep
+            c[i] = is_x ? rnd<H16>(-(xr * qrow)) : pd[i];    // admm.cpp:81  q(i,j) = -(Xref(i,j) * Q(i))
             b[i * WAVE] = cold ? 0.f : ldw<H16>(P.vz, rowbase + i * 16);
             a[i] = zdual ? 0.f : ldw<H16>(P.gy, rowbase + i * 16);
             sn[i * WAVE] = 0.f;
@@ -114,7 +113,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
     {
         if (!__any(active)) break;
         // the last permitted iteration must not overwrite d in registers: x,u of an instance that exhausts max_iter come
-        // from the d its last forward sweep used (regenerated in the epilogue); the final d itself is in the pd array
+        // from the d its last forward sweep used (regenerated in the epilogue); the final d itself is kept in pd[]
         const bool keep_d = (it == P.max_iter - 1);
         if (active)
         {
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
                     riccati_step<NX, NU, EXACT, H16>(G, is_x, p, lin_cost<EXACT, H16>(cq, rho, t1), pn, dd); // admm.cpp:19-20,80-82
                     c[i] = upd_d ? dd : c[i];
                     b[i * WAVE] = sni;                     // admm.cpp:141-142
-                    stw<H16>(P.pd, rowbase + i * 16, is_u ? dd : pn); // [p_i ; d_i] of this sweep
+                    pd[i] = is_u ? dd : pn;                // [p_i ; d_i] of this sweep (live-out only: stays in registers)
                     p = pn;
                 }
             }
@@ -221,8 +220,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             // p.col(N-1) is rewritten by every forward sweep (admm.cpp:83-84); the other columns and d were stored by the
             // last backward sweep this instance executed.  An instance that never ran one keeps its live-in p,d
             // (all zero after reset_workspace, which only marked them so).
-            if (i == N - 1) stw<H16>(P.pd, o, is_x ? pN : 0.f);
-            else if (cold && !ran_bwd) stw<H16>(P.pd, o, 0.f);
+            stw<H16>(P.pd, o, i == N - 1 ? (is_x ? pN : 0.f) : pd[i]);
             stw<H16>(P.vz, o, b[i * WAVE]);
             stw<H16>(P.vzn, o, sni);
             stw<H16>(P.gy, o, a[i]);

@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--mode", choices=["early_exit", "fixed10"], default="early_exit")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto (rowlane exact), 1 streaming, 2 rowlane exact, 3 rowlane fast")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the warm-started closed-loop extra (profiling runs: "
+                    "its launches of the same kernel would be averaged into the per-kernel statistics)")
     args = ap.parse_args()
 
     import torch
@@ -218,7 +220,7 @@ def main():
     # every MPC step = dual reset + solve + plant step + window slide on the device, replayed from one hipGraph.
     # Reported as an extra; `value` stays the cold-start solve rate above.
     closed = None
-    if rank == 0 and not args.kernel:
+    if rank == 0 and not args.kernel and not args.no_closed_loop:
         try:
             sol.reset_workspace()
             sol._check(lib.tiny_batch_set_x0_device(h, C.c_void_p(d_x0.data_ptr())))
