@@ -95,6 +95,7 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
 
     // per-instance state, all in registers: duals a, reference cost term / feed-forward, previous and current slack
     float ax[N], ay[N], cq[N], dd[N], bx[N], bz[N], sx[N], sz[N];
+    float pp[N], dl[N]; // [p_i ; d_i] of the last executed backward sweep (live-out only; the live-in values until then)
     const int rowx = (inst * N) * 16 + j, rowu = (inst * N) * 16 + NX;
     int wstart = 0;
     if (P.xref_mode == 1 && valid) wstart = P.xref_start[inst];
@@ -116,6 +117,8 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
             xr = ldw<H16>(P.xref, xref_off + i * 16);
         cq[i] = rnd<H16>(-(xr * qrow)); // admm.cpp:81
         dd[i] = (cold || i == N - 1) ? 0.f : ldw<H16>(P.pd, rowu + i * 16);
+        dl[i] = dd[i];
+        pp[i] = cold ? 0.f : ldw<H16>(P.pd, rowx + i * 16);
         bx[i] = cold ? 0.f : ldw<H16>(P.vz, rowx + i * 16);
         bz[i] = (cold || i == N - 1) ? 0.f : ldw<H16>(P.vz, rowu + i * 16);
         ax[i] = zdual ? 0.f : ldw<H16>(P.gy, rowx + i * 16);
@@ -235,8 +238,7 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
                         pn = rnd<H16>(__builtin_fmaf(Kj, lin_u, lin_x + aP)); // Kj holds -Kinf here
                     }
                     if (!keep_d) dd[i] = dnew;
-                    stw<H16>(P.pd, rowx + i * 16, pn);             // [p_i ; d_i] of this sweep
-                    if (lead) stw<H16>(P.pd, rowu + i * 16, dnew);
+                    pp[i] = pn; dl[i] = dnew;                      // [p_i ; d_i] of this sweep
                     bx[i] = sx[i]; bz[i] = sz[i];                  // admm.cpp:141-142
                     p = pn;
                 }
@@ -269,8 +271,7 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
             stw<H16>(P.xu, ox, s);
             const float lin_x = lin_cost<EXACT, H16>(cq[i], rho, sx[i] - ax[i]);
             stw<H16>(P.qr, ox, lin_x);
-            if (i == N - 1) stw<H16>(P.pd, ox, pN);
-            else if (cold && !ran_bwd) stw<H16>(P.pd, ox, 0.f);
+            stw<H16>(P.pd, ox, i == N - 1 ? pN : pp[i]);
             stw<H16>(P.vz, ox, bx[i]);
             stw<H16>(P.vzn, ox, sx[i]);
             stw<H16>(P.gy, ox, ax[i]);
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
                 const bool inp = i < N - 1; // the input-type members have N-1 columns; column N-1 of the row layout is zero
                 stw<H16>(P.xu, ou, inp ? un : 0.f);
                 stw<H16>(P.qr, ou, inp ? lin_cost<EXACT, H16>(0.f, rho, sz[i] - ay[i]) : 0.f);
-                if (i == N - 1 || (cold && !ran_bwd)) stw<H16>(P.pd, ou, 0.f);
+                stw<H16>(P.pd, ou, inp ? dl[i] : 0.f);
                 stw<H16>(P.vz, ou, inp ? bz[i] : 0.f);
                 stw<H16>(P.vzn, ou, inp ? sz[i] : 0.f);
                 stw<H16>(P.gy, ou, inp ? ay[i] : 0.f);
