@@ -143,3 +143,40 @@ def test_oracle_refuses_dims_whose_reference_result_depends_on_alignment(oracle_
     with pytest.raises(ValueError):
         O.Oracle(prob, np.float32)
     O.Oracle(tinympc.problems.random_system(8, 3, 7, seed=1), np.float32)  # nu < packet size: fine
+
+
+def test_oracle_and_host_riccati_under_address_and_ub_sanitizers(tmp_path):
+    """sanitizers run on the CPU builds.  (a) the restatement (fp32, fp64, fp16-storage instantiations and
+    the Riccati recursion) through `make -C oracle sanitize`; (b) the product's host-only Riccati routine
+    (csrc/riccati.cpp) compiled stand-alone with the same flags and driven on the cartpole model."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    r = subprocess.run(["make", "-s", "-C", str(root / "oracle"), "sanitize"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "_h16" in r.stdout and "ERROR" not in r.stderr
+    z = np.load(__import__("helpers").GOLDEN / "riccati_cartpole.npz")  # the model of examples/codegen_cartpole.cpp:22-28
+    arr = lambda a: ", ".join(repr(float(v)) for v in np.asarray(a, np.float64).T.ravel())  # column-major
+    main = tmp_path / "riccati_main.cpp"
+    main.write_text(f'''
+#include "tinympc_batch.h"
+#include <cstdio>
+int main() {{
+    double A[16] = {{{arr(z["A"])}}}, B[4] = {{{arr(z["B"])}}}, Q[4] = {{{arr(z["Q"])}}}, R[1] = {{{arr(z["R"])}}};
+    double K[4], P[16], Qi[1], Am[16], cd[4]; int it = 0;
+    int rc = tiny_riccati(4, 1, A, B, Q, R, {float(z["rho"])!r}, K, P, Qi, Am, cd, &it);
+    std::printf("rc %d iters %d K %.7f %.7f %.7f %.7f\\n", rc, it, K[0], K[1], K[2], K[3]);
+    return rc != 0 || it <= 0 || it >= 1000;
+}}
+''')
+    exe = tmp_path / "riccati_san"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        f"-I{root / 'include'}", str(main), str(root / "accelerated-tinympc_amd" / "csrc" / "riccati.cpp"),
+                        "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "iters 476" in r.stdout, r.stdout   # "Kinf converged after 476 iterations" (SURVEY.md §4)
