@@ -26,7 +26,9 @@
 namespace tinympc
 {
 
-template <int NX, int NU, int N, bool EXACT, bool H16>
+// MPC = true: the closed-loop variant (P.mpc_steps MPC steps inside one launch); a separate instantiation so that the
+// ordinary solve keeps its register allocation
+template <int NX, int NU, int N, bool EXACT, bool H16, bool MPC = false>
 __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P)
 {
     const int lane = threadIdx.x;
@@ -91,10 +93,10 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             if (i == N - 1) xrN = xr;
         }
     }
-    const float x0 = ldw<H16>(P.xu, rowbase); // x.col(0) on x rows (u rows hold stale u_0, never used as x)
+    float x0 = ldw<H16>(P.xu, rowbase); // x.col(0) on x rows (u rows hold stale u_0, never used as x)
 
     // -(Xref_{N-1}^T Pinf): constant during a solve (admm.cpp:83)
-    const float pterm = terminal_term<NX, NU, EXACT, H16>(P.mats, r16, xrN);
+    float pterm = terminal_term<NX, NU, EXACT, H16>(P.mats, r16, xrN);
 
     int st = TINY_STATUS_UNSOLVED_, itn = 1; // admm.cpp:114-115
     float r_ps = 0.f, r_pi = 0.f, r_ds = 0.f, r_di = 0.f;
@@ -108,7 +110,12 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
 
     auto lqr = [&](float s_, float ci, float &sv, float &xn) { lqr_step<NX, NU, EXACT, H16>(G, is_x, is_u, s_, ci, sv, xn); };
 
+    // Closed loop on chip: P.mpc_steps > 1 repeats {solve; advance} with the whole state staying in registers/LDS.
+    // An ordinary solve is mpc_steps == 1.
+    for (int ms = 0;; ++ms)
+    {
     bool active = valid && (P.max_iter > 0);
+    st = TINY_STATUS_UNSOLVED_; itn = 1;
     for (int it = 0; it < P.max_iter; ++it)
     {
         if (!__any(active)) break;
@@ -186,6 +193,34 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
         }
     }
 
+    if (!MPC || ms + 1 >= P.mpc_steps) break;
+    // ---------------- advance to the next MPC step (quadrotor_tracking.cpp:101-118), nothing leaves the chip ----------------
+    {
+        float sv0, x1;
+        lqr(x0, c[0], sv0, x1); // [x_0 ; u_0] of the solve that just finished, in the solver's own arithmetic
+        if (P.u0_traj && valid && is_u) P.u0_traj[((long long)ms * P.batch + inst) * NU + (r16 - NX)] = sv0;
+        if constexpr (MPC) x0 = plant_step<NX, NU>(G, sv0); // x_1 = Adyn x0 + Bdyn u_0 (:110), the plant kernel's arithmetic
+        wstart += P.window_advance;
+        const float qrow = P.mats[(2 * NX + 2 * NU) * 16 + r16];
+#pragma unroll
+        for (int i = 0; i < N; i++)
+        {
+            float cqn = c[i];
+            if (P.xref_mode == 1)
+            {
+                int row = wstart + i;
+                row = row < P.table_rows ? row : P.table_rows - 1;
+                const float xr = ldw<H16>(P.xref_table, row * 16 + r16);
+                cqn = rnd<H16>(-(xr * qrow));
+                if (i == N - 1) xrN = xr;
+            }
+            c[i] = is_x ? cqn : pd[i]; // d of the workspace = d of the last executed backward sweep
+            a[i] = 0.f;                // y = g = 0 (:106-107)
+        }
+        if (P.xref_mode == 1) pterm = terminal_term<NX, NU, EXACT, H16>(P.mats, r16, xrN);
+    }
+    }
+
     if (P.max_iter <= 0) // tiny_solve only sets status and iter (admm.cpp:114-117,151)
     {
         if (valid && r16 == 0)
@@ -226,6 +261,11 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             stw<H16>(P.gy, o, a[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (MPC) // the host's plant step continues from here
+        {
+            if (is_x) P.x0buf[inst * NX + r16] = x0;
+            if (r16 == 0 && P.xref_mode == 1) P.xref_start[inst] = wstart;
+        }
         if (r16 == 0)
         {
             P.res[4 * inst + 0] = r_ps; P.res[4 * inst + 1] = r_pi;
@@ -248,6 +288,19 @@ bool rowlane_supported(int nx, int nu, int N)
 hipError_t launch_admm_rowlane(int nx, int nu, int N, bool exact, bool h16, const RowParams &P, hipStream_t stream)
 {
     const int nblocks = (P.batch + 3) / 4;
+    if (P.mpc_steps > 1) // closed loop on chip: fp32 storage only
+    {
+        if (h16) return hipErrorInvalidValue;
+#define TINY_ROWLANE_MPC_DISPATCH(NX, NU, NN)                                                               \
+    if (nx == NX && nu == NU && N == NN)                                                                    \
+    {                                                                                                       \
+        if (exact) hipLaunchKernelGGL((admm_rowlane_kernel<NX, NU, NN, true, false, true>), dim3(nblocks), dim3(WAVE), 0, stream, P);  \
+        else hipLaunchKernelGGL((admm_rowlane_kernel<NX, NU, NN, false, false, true>), dim3(nblocks), dim3(WAVE), 0, stream, P);     \
+        return hipGetLastError();                                                                           \
+    }
+        TINY_FOR_EACH_ROWLANE(TINY_ROWLANE_MPC_DISPATCH)
+        return hipErrorInvalidValue;
+    }
 #define TINY_ROWLANE_LAUNCH(NX, NU, NN, EX, H) \
     hipLaunchKernelGGL((admm_rowlane_kernel<NX, NU, NN, EX, H>), dim3(nblocks), dim3(WAVE), 0, stream, P)
 #define TINY_ROWLANE_DISPATCH(NX, NU, NN)                                                                   \

@@ -214,6 +214,20 @@ __device__ __forceinline__ void lqr_step(const RowGains<NX, NU> &G, bool is_x, b
     }
 }
 
+// plant step of the closed loop (examples/quadrotor_hovering.cpp:110): xn = Adyn*x + Bdyn*u with sv = [x ; u], always in
+// separately rounded sequential-order arithmetic — what the host-launched plant kernel computes — whatever the mode of
+// the solver, so that the on-chip closed loop and the step-by-step one continue from identical states
+template <int NX, int NU>
+__device__ __forceinline__ float plant_step(const RowGains<NX, NU> &G, float sv)
+{
+    using PL = RowPlans<NX, NU>;
+    static_assert(PL::FWD_XA == PLAN_SEQ && PL::FWD_XB == PLAN_SEQ, "the plant kernel sums sequentially");
+    float t[NX], t2[NU];
+    dpp_products<0, NX>(t, sv, G.M1);
+    dpp_products<NX, NU>(t2, sv, G.M2);
+    return reduce<PLAN_SEQ>(t) + reduce<PLAN_SEQ>(t2);
+}
+
 // backward_pass_grad step (admm.cpp:19-20): from p = p_{i+1} (x rows) and lin = [q_i ; r_i] compute
 //   pn = p_i = q_i + AmBKt*p_{i+1} - Kinf^T*r_i (x rows),   dd = d_i = Quu_inv*(Bdyn^T*p_{i+1} + r_i) (u rows)
 template <int NX, int NU, bool EXACT, bool H16 = false>

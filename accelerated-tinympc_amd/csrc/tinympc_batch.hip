@@ -148,10 +148,12 @@ __global__ void plant_step_kernel(float *__restrict__ x0buf, float *__restrict__
     float xn[64];
     for (int i = 0; i < nx; i++)
     {
-        float acc = 0.f;
-        for (int k = 0; k < nx; k++) acc += A[k * nx + i] * x0[k];
-        float acc2 = 0.f;
-        for (int m = 0; m < nu; m++) acc2 += Bm[m * nx + i] * get_elem(uarr, idx_of(layout, g, 1, b, 0, m), h16);
+        // sequential sums starting from the first product: the order forward_pass uses for nx % 4 == 0 (admm.cpp:35), so
+        // that the on-chip closed loop of admm_rowlane.hip (which gets x_1 from its own forward step) continues bit-identically
+        float acc = A[i] * x0[0];
+        for (int k = 1; k < nx; k++) acc += A[k * nx + i] * x0[k];
+        float acc2 = Bm[i] * get_elem(uarr, idx_of(layout, g, 1, b, 0, 0), h16);
+        for (int m = 1; m < nu; m++) acc2 += Bm[m * nx + i] * get_elem(uarr, idx_of(layout, g, 1, b, 0, m), h16);
         xn[i] = acc + acc2;
     }
     for (int i = 0; i < nx; i++)
@@ -669,6 +671,7 @@ void fill_row_params(TinyBatch *tb, RowParams &P, bool exact)
     P.bounds = tb->r_bounds;
     P.mats = exact ? tb->mats_exact : tb->mats_fast;
     P.res = tb->res; P.status = tb->status; P.iter = tb->iter; P.n_unsolved = tb->n_unsolved;
+    P.mpc_steps = 1; P.window_advance = 0; P.u0_traj = nullptr; P.x0buf = tb->x0buf;
 }
 
 // One of the six step functions of admm.hpp:10-18 over the whole batch (admm_steps.hip).
@@ -1217,31 +1220,49 @@ int tiny_batch_mpc_step_async(TinyBatch *tb, int window_advance)
     return enqueue_plant_step(tb, window_advance);
 }
 
-// `steps` closed-loop MPC steps back to back.  The launch sequence (counter reset, solve kernel, plant kernel) x steps is
-// captured ONCE into a hipGraph and replayed: for small batches and warm-started solves of a few iterations the
-// per-launch overhead is a large part of a step.
-int tiny_batch_mpc_run_async(TinyBatch *tb, int steps, int window_advance)
+// `steps` closed-loop MPC steps back to back; d_u0_traj (device, [steps][B][nu], may be NULL) receives u.col(0) of every
+// step.  Two implementations with identical results:
+//  * on chip (the unrolled row kernel, fp32 storage): ONE launch runs all the steps, the state never leaves registers/LDS
+//    between solves (admm_rowlane.hip, MPC = true); the host only adds the plant step of the last solve;
+//  * otherwise the launch sequence (counter reset, solve kernel, plant kernel) x steps is captured ONCE into a hipGraph and
+//    replayed, which removes the per-launch overhead that dominates small batches with short warm-started solves.
+int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, float *d_u0_traj)
 {
     CHECK_TB(tb);
     if (steps < 1) return fail(TINY_BATCH_EINVAL, "tiny_batch_mpc_run_async: steps must be >= 1");
     if (tb->nx > 64) return fail(TINY_BATCH_EUNSUPPORTED, "mpc_run supports nx <= 64");
     if (tb->max_iter <= 0) return fail(TINY_BATCH_EINVAL, "tiny_batch_mpc_run_async needs max_iter > 0");
     TRY(set_device(tb));
+    TRY(flush_pending(tb)); // every solve of the run starts from "duals reset, workspace warm"
+    tb->duals_zero_pending = true;
+    int v = 0;
+    TRY(prepare_solve(tb, &v));
+    const size_t u0n = (size_t)tb->batch * tb->nu;
+    if (v != VAR_STREAM && row_family(tb) == 0 && !tb->h16 && steps > 1)
+    {
+        RowParams P;
+        fill_row_params(tb, P, v == VAR_ROW_EXACT);
+        P.mpc_steps = steps; P.window_advance = window_advance; P.u0_traj = d_u0_traj;
+        HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, sizeof(int), tb->stream));
+        hipError_t e = launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, false, P, tb->stream);
+        if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+        if (d_u0_traj) TRY(launch_unpack(tb, work_ptr(tb, TINY_ARR_U), d_u0_traj + (size_t)(steps - 1) * u0n, tb->layout, 1, tb->batch, 0, 1));
+        TRY(enqueue_plant_step(tb, window_advance));
+        tb->duals_zero_pending = tb->cold_pending = false;
+        tb->ev_valid = false;
+        return 0;
+    }
     if (!tb->stream) // stream capture is not allowed on the null stream
     {
         HIP_TRY(hipStreamSynchronize(nullptr));
         if (!tb->own_stream) HIP_TRY(hipStreamCreateWithFlags(&tb->own_stream, hipStreamNonBlocking));
         tb->stream = tb->own_stream;
     }
-    TRY(flush_pending(tb)); // the captured solves all start from "duals reset, workspace warm"
-    tb->duals_zero_pending = true;
-    int v = 0;
-    TRY(prepare_solve(tb, &v));
     // the graph bakes in kernel arguments: rebuild it whenever anything they depend on may have changed
-    char sig[256];
-    snprintf(sig, sizeof sig, "%d|%d|%d|%s|%d|%d|%g|%g|%d|%d|%p|%p|%p|%d|%p", steps, window_advance, v, tb->kname.c_str(), tb->max_iter,
+    char sig[288];
+    snprintf(sig, sizeof sig, "%d|%d|%d|%s|%d|%d|%g|%g|%d|%d|%p|%p|%p|%d|%p|%p", steps, window_advance, v, tb->kname.c_str(), tb->max_iter,
              tb->check_termination, (double)tb->abs_pri_tol, (double)tb->abs_dua_tol, tb->xref_mode, tb->table_rows, (void *)tb->pair[0],
-             (void *)tb->arr[0], (void *)tb->r_bounds, (int)tb->h16, (void *)tb->stream);
+             (void *)tb->arr[0], (void *)tb->r_bounds, (int)tb->h16, (void *)tb->stream, (void *)d_u0_traj);
     if (!tb->graph_exec || tb->graph_sig != sig)
     {
         if (tb->graph_exec) { (void)hipGraphExecDestroy(tb->graph_exec); tb->graph_exec = nullptr; }
@@ -1252,6 +1273,7 @@ int tiny_batch_mpc_run_async(TinyBatch *tb, int steps, int window_advance)
         {
             tb->duals_zero_pending = true;
             rc = enqueue_solve(tb, v, false);
+            if (rc == 0 && d_u0_traj) rc = launch_unpack(tb, work_ptr(tb, TINY_ARR_U), d_u0_traj + (size_t)k * u0n, tb->layout, 1, tb->batch, 0, 1);
             if (rc == 0) rc = enqueue_plant_step(tb, window_advance);
         }
         hipError_t ec = hipStreamEndCapture(tb->stream, &graph);
@@ -1266,6 +1288,11 @@ int tiny_batch_mpc_run_async(TinyBatch *tb, int steps, int window_advance)
     tb->duals_zero_pending = tb->cold_pending = false;
     tb->ev_valid = false;
     return 0;
+}
+
+int tiny_batch_mpc_run_async(TinyBatch *tb, int steps, int window_advance)
+{
+    return tiny_batch_mpc_run_traj_async(tb, steps, window_advance, nullptr);
 }
 
 int tiny_batch_get_x0(TinyBatch *tb, float *x0)

@@ -89,12 +89,17 @@ struct RowParams
     const float *xref;           // [batch or 1][N][16]
     unsigned xref_inst_stride;   // floats between instances (0 = shared)
     const float *xref_table;     // [rows][16]
-    const int *xref_start;
+    int *xref_start;             // [batch] window start; advanced by the closed-loop kernels
     int table_rows;
     const float *bounds;         // [N][16][2] = {lo, hi}; +-inf where a bound is disabled or the row is unused
     const float *mats;           // [3nx + 2nu + 1][16] gain rows per lane (see pack_row_mats)
     float *res;
     int *status, *iter, *n_unsolved;
+    // closed loop on chip (admm_rowlane.hip): mpc_steps > 1 runs that many MPC steps (solve; x0 <- Adyn x0 + Bdyn u0;
+    // window += window_advance; y = g = 0) inside one launch, the state never leaving registers/LDS in between
+    int mpc_steps, window_advance;
+    float *u0_traj;              // [mpc_steps][batch][nu] or NULL: u.col(0) of every step
+    float *x0buf;                // [batch][nx]: x0 of the LAST solve of the launch (the host's plant step reads it)
 };
 
 // (nx, nu) pairs with single-function kernels (admm_steps.hip), any N

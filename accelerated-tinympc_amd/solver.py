@@ -65,7 +65,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch_reset_workspace": [P],
         "tiny_batch_set_x0_device": [P, P], "tiny_batch_get_u0_device": [P, P],
         "tiny_batch_mpc_step_async": [P, C.c_int], "tiny_batch_get_x0": [P, F],
-        "tiny_batch_mpc_run_async": [P, C.c_int, C.c_int],
+        "tiny_batch_mpc_run_async": [P, C.c_int, C.c_int], "tiny_batch_mpc_run_traj_async": [P, C.c_int, C.c_int, P],
         "tiny_batch_enable_timing": [P, C.c_int], "tiny_batch_last_solve_ms": [P, F],
         "tiny_batch_select_kernel": [P, C.c_int], "tiny_batch_set_storage": [P, C.c_int],
         "tiny_batch_set_row_kernel": [P, C.c_int],

@@ -217,7 +217,8 @@ def main():
         sol.select_kernel(0)
 
     # warm-started closed loop (how the reference's examples actually run the solver, quadrotor_tracking.cpp:93-118):
-    # every MPC step = dual reset + solve + plant step + window slide on the device, replayed from one hipGraph.
+    # every MPC step = dual reset + solve + plant step + window slide, all `ksteps` of them inside one kernel launch with
+    # the state staying on chip between solves (tiny_batch_mpc_run_async).
     # Reported as an extra; `value` stays the cold-start solve rate above.
     closed = None
     if rank == 0 and not args.kernel and not args.no_closed_loop:
@@ -226,7 +227,7 @@ def main():
             sol._check(lib.tiny_batch_set_x0_device(h, C.c_void_p(d_x0.data_ptr())))
             sol.set_xref_window(table, start)
             ksteps = 20
-            sol.mpc_run_async(ksteps, 1)      # builds the graph, settles the warm start
+            sol.mpc_run_async(ksteps, 1)      # settles the warm start
             sol.synchronize()
             t_c = time.perf_counter()
             sol.mpc_run_async(ksteps, 1)
@@ -235,7 +236,7 @@ def main():
             itc, stc, _ = sol.get_status()
             closed = {"mpc_steps": ksteps, "ms_per_mpc_step": dt_c / ksteps * 1e3, "solves_per_s": B * ksteps / dt_c,
                       "mean_iters_last_step": float(itc.mean()), "frac_converged_last_step": float(np.mean(stc == 1)),
-                      "note": "warm-started tracking loop on the device (tiny_batch_mpc_run_async), wall time of one graph replay"}
+                      "note": "warm-started tracking loop on the device (tiny_batch_mpc_run_async: one launch, state on chip between solves), wall time"}
         except Exception as e:  # noqa: BLE001
             closed = {"error": f"{type(e).__name__}: {e}"}
 

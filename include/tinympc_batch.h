@@ -151,10 +151,13 @@ extern "C"
      *   x.col(0) = x0;  [window start += window_advance];  y = 0, g = 0;  tiny_solve;  x0 = Adyn*x0 + Bdyn*u.col(0)
      * x0 lives in an internal device buffer seeded by tiny_batch_set_x0(). */
     int tiny_batch_mpc_step_async(TinyBatch *tb, int window_advance);
-    /* `steps` such MPC steps back to back (same window_advance each).  The launch sequence is captured once into a
-     * hipGraph and replayed, which removes the per-launch overhead that dominates small batches with warm-started solves
-     * of a few iterations.  A handle still on the null stream is moved to a stream of its own (capture needs one). */
+    /* `steps` such MPC steps back to back (same window_advance each), results identical to `steps` calls of
+     * tiny_batch_mpc_step_async.  Where the unrolled row kernel applies (fp32 storage) ONE launch runs all the steps with
+     * the state staying on chip between solves; otherwise the launch sequence is captured once into a hipGraph and
+     * replayed (a handle still on the null stream is then moved to a stream of its own: capture needs one).
+     * The _traj form also records u.col(0) of every step into a DEVICE buffer [steps][B][nu]. */
     int tiny_batch_mpc_run_async(TinyBatch *tb, int steps, int window_advance);
+    int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, float *d_u0_traj);
     int tiny_batch_get_x0(TinyBatch *tb, float *x0 /*[B][nx]*/);
 
     /* ---- measurement ------------------------------------------------------------------------- */

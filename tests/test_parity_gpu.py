@@ -911,11 +911,12 @@ def test_wave_kernel_vs_oracle(tinympc, oracle_mod, B):
         sol.close()
 
 
-@pytest.mark.parametrize("variant_name", ["row_exact", "stream"])
-def test_graph_captured_mpc_run_equals_step_by_step(tinympc, variant_name):
-    """tiny_batch_mpc_run_async(steps) — the (solve + plant step) x steps sequence captured once into a hipGraph and
-    replayed — leaves exactly the state that `steps` calls of tiny_batch_mpc_step_async leave; a second replay of the
-    same graph continues the trajectory, and a change of settings rebuilds the graph."""
+@pytest.mark.parametrize("variant_name", ["row_exact", "row_fast", "loop_exact", "stream"])
+def test_mpc_run_equals_step_by_step(tinympc, variant_name):
+    """tiny_batch_mpc_run_async(steps) leaves exactly the state that `steps` calls of tiny_batch_mpc_step_async leave, in both
+    implementations: the on-chip closed loop of the unrolled row kernel (row_* variants: one launch, the state stays in
+    registers/LDS between solves) and the (solve + plant step) x steps sequence captured once into a hipGraph (the other
+    kernels).  A second run continues the trajectory; a change of settings rebuilds the graph."""
     pr = tinympc.problems
     prob = pr.quadrotor(20, 30)
     B = 48
@@ -981,3 +982,40 @@ def test_quadlane_kernel_vs_oracle(tinympc, oracle_mod, B):
                 if not exact:
                     sol.set_state(st)
             sol.close()
+
+
+@pytest.mark.parametrize("variant_name", ["row_exact", "loop_exact"])
+def test_mpc_run_records_the_input_trajectory(tinympc, variant_name):
+    """tiny_batch_mpc_run_traj_async writes u.col(0) of every MPC step to a device buffer [steps][B][nu]: equal to what a
+    host loop reads with get_u after every step (on-chip loop and graph replay alike); windows that run off the end of
+    the trajectory table clamp like the reference's would."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    pr = tinympc.problems
+    prob = pr.quadrotor(20, 30)
+    B, K = 37, 9
+    x0, table, start = pr.tracking_batch(B, 30, seed=21)
+    start = np.minimum(start + 40, 301 - 30).astype(np.int32)  # some windows reach the end of the table within K steps
+    bnds = pr.bounds_arrays(prob)
+    a = make_solver(tinympc, prob, B, None, None, variant_name, bnds)
+    b = make_solver(tinympc, prob, B, None, None, variant_name, bnds)
+    for s in (a, b):
+        s.set_xref_window(table, start)
+        s.set_x0(x0)
+    traj = np.zeros((K, B, 4), np.float32)
+    d_traj = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d_traj), ctypes.c_size_t(traj.nbytes)) == 0
+    a._check(a.lib.tiny_batch_mpc_run_traj_async(a._h, K, 1, d_traj))
+    a.synchronize()
+    assert hip.hipMemcpy(traj.ctypes.data_as(ctypes.c_void_p), d_traj, ctypes.c_size_t(traj.nbytes), 2) == 0
+    for k in range(K):
+        b.reset_dual_variables(); b.solve()
+        assert np.array_equal(traj[k], b.get_u()[:, 0]), f"step {k}"
+        # advance b by hand: x_1 of the solve IS the plant step (the plant is the model, hovering.cpp:110); a window that
+        # runs off the table keeps repeating its last row
+        x_next = b.get_x()[:, 1]
+        padded = np.vstack([table, np.repeat(table[-1:], K + 1, 0)])
+        b.set_xref(pr.expand_windows(padded, start + k + 1, 30))
+        b.set_x0(x_next)
+    hip.hipFree(d_traj)
+    a.close(); b.close()
