@@ -62,7 +62,8 @@ __device__ __forceinline__ float quad_max(float v)
     return v;
 }
 
-template <int N, bool EXACT, bool H16>
+// MPC = true: closed-loop variant (P.mpc_steps MPC steps in one launch, the state staying in registers; see admm_rowlane.hip)
+template <int N, bool EXACT, bool H16, bool MPC = false>
 __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
 {
     constexpr int NX = 4;
@@ -126,14 +127,14 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
         sx[i] = 0.f; sz[i] = 0.f;
         if (i == N - 1) xrN = xr;
     }
-    const float x0 = ldw<H16>(P.xu, rowx);
-    float pterm;
-    {
+    float x0 = ldw<H16>(P.xu, rowx);
+    auto terminal = [&](float xr_last) { // -(Xref_{N-1}^T Pinf) (admm.cpp:83): packet reduction
         float t[4];
-        quad_products(t, xrN, PT); // -(Xref_{N-1}^T Pinf) (admm.cpp:83): packet reduction
-        if constexpr (EXACT) pterm = rnd<H16>(-((t[0] + t[2]) + (t[1] + t[3])));
-        else pterm = rnd<H16>(-(((t[0] + t[1]) + t[2]) + t[3]));
-    }
+        quad_products(t, xr_last, PT);
+        if constexpr (EXACT) return rnd<H16>(-((t[0] + t[2]) + (t[1] + t[3])));
+        else return rnd<H16>(-(((t[0] + t[1]) + t[2]) + t[3]));
+    };
+    float pterm = terminal(xrN);
 
     // one forward_pass step (admm.cpp:31,35): from x_i (row j) and d_i -> u_i (all lanes) and x_{i+1} (row j)
     auto lqr = [&](float s, float di, float &un, float &xn) {
@@ -162,7 +163,10 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
     }
     float pN = 0.f;
     bool ran_bwd = false;
+    for (int ms = 0;; ++ms) // MPC steps of the closed-loop variant; an ordinary solve runs the body once
+    {
     bool active = valid && (P.max_iter > 0);
+    st = TINY_STATUS_UNSOLVED_; itn = 1;
     for (int it = 0; it < P.max_iter; ++it)
     {
         if (!__any(active)) break;
@@ -245,6 +249,37 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
             }
         }
     }
+    if (!MPC || ms + 1 >= P.mpc_steps) break;
+    // ---------------- advance to the next MPC step on chip (examples/codegen_cartpole.cpp closed loop) ----------------
+    {
+        float u0v, x1;
+        lqr(x0, dd[0], u0v, x1); // u_0 of the solve that just finished, in the solver's own arithmetic
+        if (P.u0_traj && valid && lead) P.u0_traj[(long long)ms * P.batch + inst] = u0v;
+        if constexpr (MPC)
+        {
+            // plant step x_1 = Adyn x0 + Bdyn u_0 in the plant kernel's (sequential, separately rounded) arithmetic
+            float tK[4], tA[4];
+            quad_products2(tK, tA, x0, Kneg, Arow);
+            x0 = (((tA[0] + tA[1]) + tA[2]) + tA[3]) + Bj * u0v;
+        }
+        wstart += P.window_advance;
+#pragma unroll
+        for (int i = 0; i < N; i++)
+        {
+            if (P.xref_mode == 1)
+            {
+                int row = wstart + i;
+                row = row < P.table_rows ? row : P.table_rows - 1;
+                const float xr = ldw<H16>(P.xref_table, row * 16 + j);
+                cq[i] = rnd<H16>(-(xr * qrow));
+                if (i == N - 1) xrN = xr;
+            }
+            dd[i] = dl[i];           // d of the workspace = d of the last executed backward sweep
+            ax[i] = 0.f; ay[i] = 0.f; // y = g = 0
+        }
+        if (P.xref_mode == 1) pterm = terminal(xrN);
+    }
+    }
 
     if (P.max_iter <= 0) // tiny_solve only sets status and iter (admm.cpp:114-117,151)
     {
@@ -287,6 +322,11 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
             }
             s = xn;
         }
+        if (MPC) // the host's plant step continues from here
+        {
+            P.x0buf[inst * NX + j] = x0;
+            if (lead && P.xref_mode == 1) P.xref_start[inst] = wstart;
+        }
         if (lead)
         {
             P.res[4 * inst + 0] = r_ps; P.res[4 * inst + 1] = r_pi;
@@ -312,6 +352,19 @@ bool quadlane_supported(int nx, int nu, int N)
 hipError_t launch_admm_quadlane(int N, bool exact, bool h16, const RowParams &P, hipStream_t stream)
 {
     const int nblocks = (P.batch + 15) / 16;
+    if (P.mpc_steps > 1) // closed loop on chip: fp32 storage only
+    {
+        if (h16) return hipErrorInvalidValue;
+#define TINY_QUADLANE_MPC_DISPATCH(NN)                                                                                   \
+    if (N == NN)                                                                                                         \
+    {                                                                                                                    \
+        if (exact) hipLaunchKernelGGL((admm_quadlane_kernel<NN, true, false, true>), dim3(nblocks), dim3(WAVE), 0, stream, P);  \
+        else hipLaunchKernelGGL((admm_quadlane_kernel<NN, false, false, true>), dim3(nblocks), dim3(WAVE), 0, stream, P);      \
+        return hipGetLastError();                                                                                        \
+    }
+        TINY_FOR_EACH_QUADLANE(TINY_QUADLANE_MPC_DISPATCH)
+        return hipErrorInvalidValue;
+    }
 #define TINY_QUADLANE_LAUNCH(NN, EX, H) \
     hipLaunchKernelGGL((admm_quadlane_kernel<NN, EX, H>), dim3(nblocks), dim3(WAVE), 0, stream, P)
 #define TINY_QUADLANE_DISPATCH(NN)                                \

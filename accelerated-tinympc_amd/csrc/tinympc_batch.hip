@@ -1222,7 +1222,7 @@ int tiny_batch_mpc_step_async(TinyBatch *tb, int window_advance)
 
 // `steps` closed-loop MPC steps back to back; d_u0_traj (device, [steps][B][nu], may be NULL) receives u.col(0) of every
 // step.  Two implementations with identical results:
-//  * on chip (the unrolled row kernel, fp32 storage): ONE launch runs all the steps, the state never leaves registers/LDS
+//  * on chip (the unrolled row kernel and the quad kernel, fp32 storage): ONE launch runs all the steps, the state never leaves registers/LDS
 //    between solves (admm_rowlane.hip, MPC = true); the host only adds the plant step of the last solve;
 //  * otherwise the launch sequence (counter reset, solve kernel, plant kernel) x steps is captured ONCE into a hipGraph and
 //    replayed, which removes the per-launch overhead that dominates small batches with short warm-started solves.
@@ -1238,13 +1238,15 @@ int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, 
     int v = 0;
     TRY(prepare_solve(tb, &v));
     const size_t u0n = (size_t)tb->batch * tb->nu;
-    if (v != VAR_STREAM && row_family(tb) == 0 && !tb->h16 && steps > 1)
+    const int fam = v != VAR_STREAM ? row_family(tb) : -1;
+    if ((fam == 0 || fam == 4) && !tb->h16 && steps > 1)
     {
         RowParams P;
         fill_row_params(tb, P, v == VAR_ROW_EXACT);
         P.mpc_steps = steps; P.window_advance = window_advance; P.u0_traj = d_u0_traj;
         HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, sizeof(int), tb->stream));
-        hipError_t e = launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, false, P, tb->stream);
+        hipError_t e = fam == 0 ? launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, false, P, tb->stream)
+                                : launch_admm_quadlane(tb->N, v == VAR_ROW_EXACT, false, P, tb->stream);
         if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
         if (d_u0_traj) TRY(launch_unpack(tb, work_ptr(tb, TINY_ARR_U), d_u0_traj + (size_t)(steps - 1) * u0n, tb->layout, 1, tb->batch, 0, 1));
         TRY(enqueue_plant_step(tb, window_advance));

@@ -1019,3 +1019,38 @@ def test_mpc_run_records_the_input_trajectory(tinympc, variant_name):
         b.set_x0(x_next)
     hip.hipFree(d_traj)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_mpc_run_on_chip_cartpole(tinympc, exact):
+    """The on-chip closed loop of the four-lanes-per-instance kernel (cartpole): K MPC steps in one launch leave the state
+    of K step-by-step calls, with a per-instance time-varying reference held fixed and with a sliding window."""
+    pr = tinympc.problems
+    prob = pr.cartpole(10)
+    B, K = 53, 12
+    rng = np.random.default_rng(3)
+    x0 = (np.array([0, 0, 0.1, 0], np.float32) + rng.uniform(-0.05, 0.05, size=(B, 4))).astype(np.float32)
+    table = (rng.standard_normal((60, 4)) * 0.02).astype(np.float32)
+    start = rng.integers(0, 30, size=B).astype(np.int32)
+    for windowed in (False, True):
+        sols = []
+        for _ in range(2):
+            s = tinympc.TinyBatchSolver(prob, B, settings=dict(max_iter=60))
+            s.select_kernel(2 if exact else 3)
+            assert s.kernel_name().startswith("quadlane"), s.kernel_name()
+            s.set_bounds(*pr.bounds_arrays(prob))
+            if windowed:
+                s.set_xref_window(table, start)
+            else:
+                s.set_xref(pr.expand_windows(table, start, 10))
+            s.set_x0(x0)
+            sols.append(s)
+        a, b = sols
+        a.mpc_run_async(K, 1 if windowed else 0)
+        for _ in range(K):
+            b.mpc_step_async(1 if windowed else 0)
+        sa, sb = a.get_state(), b.get_state()
+        for k in STATE_ORDER + SCALARS:
+            assert np.array_equal(sa[k], sb[k]), f"windowed={windowed}: {k}"
+        assert np.array_equal(a.get_x0(), b.get_x0())
+        a.close(); b.close()
