@@ -1054,3 +1054,40 @@ def test_mpc_run_on_chip_cartpole(tinympc, exact):
             assert np.array_equal(sa[k], sb[k]), f"windowed={windowed}: {k}"
         assert np.array_equal(a.get_x0(), b.get_x0())
         a.close(); b.close()
+
+
+def test_kernel_selection_and_option_errors(tinympc):
+    """Every option that cannot be honoured is refused with a TinyBatchError and leaves the handle usable."""
+    pr = tinympc.problems
+    q17 = tinympc.TinyBatchSolver(pr.quadrotor(20, 17), 8)         # no unrolled instantiation for N = 17
+    assert q17.kernel_name().startswith("rowloop")
+    for bad in (1, 4, 5, -1):
+        with pytest.raises(tinympc.TinyBatchError):
+            q17.set_row_kernel(bad)
+    q17.set_row_kernel(3); assert q17.kernel_name().startswith("rowstream")
+    q17.set_row_kernel(0); assert q17.kernel_name().startswith("rowloop")
+    with pytest.raises(tinympc.TinyBatchError):
+        q17.set_storage(8)
+    with pytest.raises(tinympc.TinyBatchError):
+        q17.mpc_run_async(0, 0)
+    q17.close()
+    q40 = tinympc.TinyBatchSolver(pr.quadrotor(20, 40), 8)         # N > 32: only the streaming row kernel
+    assert q40.kernel_name().startswith("rowstream")
+    with pytest.raises(tinympc.TinyBatchError):
+        q40.set_row_kernel(2)
+    q40.close()
+    r = tinympc.TinyBatchSolver(pr.random_system(32, 16, 50), 4)    # wave-per-instance class
+    assert r.kernel_name().startswith("wavestream")
+    with pytest.raises(tinympc.TinyBatchError):
+        r.set_storage(16)                                          # fp16 storage: row kernels only
+    with pytest.raises(tinympc.TinyBatchError):
+        r.set_row_kernel(1)
+    with pytest.raises(tinympc.TinyBatchError):
+        r.forward_pass()                                           # single-function kernels: nx + nu <= 16
+    r.select_kernel(1); assert r.kernel_name() == "stream<8,4>"
+    r.close()
+    a = tinympc.TinyBatchSolver(pr.cartpole(10), 4)
+    with pytest.raises(tinympc.TinyBatchError):
+        tinympc.solve_group([a, a])                                # the same handle twice
+    assert tinympc.solve_group([a]) >= 0                           # a group of one is an ordinary solve
+    a.close()
