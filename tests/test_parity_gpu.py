@@ -516,12 +516,13 @@ def test_step_functions_individually(tinympc, oracle_mod, case, exact):
     sol.close()
 
 
-@pytest.mark.parametrize("case", [("quad", 5), ("quad", 17), ("quad", 32), ("quad", 33), ("quad", 45), ("cartpole", 25),
-                                  ("cartpole", 40), ("odd", 12), ("odd", 2)])
+@pytest.mark.parametrize("case", [("quad", 5), ("quad", 17), ("quad", 20), ("quad", 25), ("quad", 32), ("quad", 33), ("quad", 45),
+                                  ("cartpole", 25), ("cartpole", 40), ("odd", 12), ("odd", 2)])
 @pytest.mark.parametrize("variant_name", ["row_exact", "row_fast"])
 def test_any_horizon_row_kernel(tinympc, oracle_mod, case, variant_name):
-    """Horizons without an unrolled instantiation: N <= 32 runs on the rolled-loop register-resident kernel (rowloop),
-    longer horizons on the any-N row kernel with the state in HBM (rowstream); both stay bitwise in exact arithmetic.
+    """Horizons other than the examples' 10 and 30: a few have an unrolled instantiation (rowlane), otherwise N <= 32 runs on
+    the rolled-loop register-resident kernel (rowloop) and longer horizons on the any-N row kernel with the state in HBM
+    (rowstream); all stay bitwise in exact arithmetic.
     Cold start, then a warm start with reset duals; early exit."""
     O, pr = oracle_mod, tinympc.problems
     exact = VARIANTS[variant_name][1]
@@ -536,7 +537,8 @@ def test_any_horizon_row_kernel(tinympc, oracle_mod, case, variant_name):
     bnds = pr.bounds_arrays(prob)
     settings = dict(O.DEFAULT_SETTINGS, max_iter=60)
     sol = make_solver(tinympc, prob, B, settings, xref, variant_name, bnds)
-    assert sol.kernel_name().startswith("rowloop" if N <= 32 else "rowstream"), sol.kernel_name()
+    unrolled = (kind, N) in (("quad", 20), ("quad", 25))  # TINY_FOR_EACH_ROWLANE
+    assert sol.kernel_name().startswith("rowlane" if unrolled else "rowloop" if N <= 32 else "rowstream"), sol.kernel_name()
     orc = O.Oracle(prob, np.float32, settings)
     st = O.new_state(B, nx, nu, N)
     st["x"][:, 0] = x0
