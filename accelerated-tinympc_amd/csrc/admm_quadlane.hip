@@ -84,7 +84,7 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
     for (int k = 0; k < 4; k++)
     {
         Arow[k] = P.mats[k * 16 + j];        // Adyn(j, k)
-        Kneg[k] = P.mats[k * 16 + NX];       // -Kinf(0, k)
+        Kneg[k] = P.mats[k * 16 + NX];       // Kinf(0, k) (exact) / -Kinf(0, k) (fast)
         Am[k] = P.mats[(5 + k) * 16 + j];    // AmBKt(j, k)
         Bcol[k] = P.mats[(5 + k) * 16 + NX]; // Bdyn(k, 0)
         PT[k] = P.mats[(11 + k) * 16 + j];   // Pinf(k, j)
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
         {
             float tK[4], tA[4];
             quad_products2(tK, tA, s, Kneg, Arow);
-            un = rnd<H16>(((tK[0] + tK[2]) + (tK[1] + tK[3])) - di); // the gains hold -Kinf: (-(K x)) - d
+            un = rnd<H16>(-((tK[0] + tK[2]) + (tK[1] + tK[3])) - di); // -(K x) - d: the sum is negated, like the reference
             xn = rnd<H16>((((tA[0] + tA[1]) + tA[2]) + tA[3]) + Bj * un);
         }
         else
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
                 for (int i = N - 2; i >= 0; i--)
                 {
                     const float lin_x = lin_cost<EXACT, H16>(cq[i], rho, sx[i] - ax[i]);  // q_i (row j)   admm.cpp:81-82
-                    const float lin_u = lin_cost<EXACT, H16>(0.f, rho, sz[i] - ay[i]);    // r_i           admm.cpp:80
+                    const float lin_u = lin_cost<EXACT, H16>(-0.f, rho, sz[i] - ay[i]);    // r_i           admm.cpp:80
                     float dnew, pn;
                     if constexpr (EXACT)
                     {
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
             {
                 const bool inp = i < N - 1; // the input-type members have N-1 columns; column N-1 of the row layout is zero
                 stw<H16>(P.xu, ou, inp ? un : 0.f);
-                stw<H16>(P.qr, ou, inp ? lin_cost<EXACT, H16>(0.f, rho, sz[i] - ay[i]) : 0.f);
+                stw<H16>(P.qr, ou, inp ? lin_cost<EXACT, H16>(-0.f, rho, sz[i] - ay[i]) : 0.f);
                 stw<H16>(P.pd, ou, inp ? dl[i] : 0.f);
                 stw<H16>(P.vz, ou, inp ? bz[i] : 0.f);
                 stw<H16>(P.vzn, ou, inp ? sz[i] : 0.f);

@@ -38,7 +38,6 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
     const bool is_x = r16 < NX;
     const bool is_u = (r16 >= NX) && (r16 < NX + NU);
     const float rho = P.rho;
-    const float maskx = is_x ? 1.f : 0.f;
 
     // ---- box bounds of the whole horizon, shared by the batch: LDS table [N][16] of {lo, hi} ----
     __shared__ float2 bnd[N * 16];
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
                     const float sni = sn_pref;
                     sn_pref = sn[(i > 0 ? i - 1 : 0) * WAVE]; // LDS read one step ahead
                     const float t1 = sni - a[i];
-                    const float cq = c[i] * maskx;         // x rows: -(Xref.*Q) ; u rows: 0 (x*1 and d*0 are exact)
+                    const float cq = cost_term(c[i], is_x); // x rows: -(Xref.*Q) ; u rows: -0
                     float pn, dd;
                     riccati_step<NX, NU, EXACT, H16>(G, is_x, p, lin_cost<EXACT, H16>(cq, rho, t1), pn, dd); // admm.cpp:19-20,80-82
                     c[i] = upd_d ? dd : c[i];
@@ -249,7 +248,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             s = xn;
             const float sni = sn[i * WAVE];
             const float t1 = sni - a[i];
-            const float cq = c[i] * maskx;
+            const float cq = cost_term(c[i], is_x);
             const float lin = lin_cost<EXACT, H16>(cq, rho, t1);
             stw<H16>(P.qr, o, (i < N - 1 || is_x) ? lin : 0.f);
             // p.col(N-1) is rewritten by every forward sweep (admm.cpp:83-84); the other columns and d were stored by the

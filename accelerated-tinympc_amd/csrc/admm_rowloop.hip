@@ -34,7 +34,6 @@ __global__ __launch_bounds__(WAVE, 3) void admm_rowloop_kernel(const RowParams P
     const bool is_u = (r16 >= NX) && (r16 < NX + NU);
     const int N = P.N;
     const float rho = P.rho;
-    const float maskx = is_x ? 1.f : 0.f;
 
     float2 *bnd = reinterpret_cast<float2 *>(lds); // [N][16] {lo, hi}, shared by the batch
     float *b = lds + N * 32 + lane;                 // b[i * WAVE]
@@ -155,7 +154,7 @@ __global__ __launch_bounds__(WAVE, 3) void admm_rowloop_kernel(const RowParams P
                 {
                     const float ci = c[i];
                     const float tb = sn_cur - a[i];
-                    const float cq = ci * maskx; // x rows: -(Xref.*Q) ; u rows: 0
+                    const float cq = cost_term(ci, is_x); // x rows: -(Xref.*Q) ; u rows: -0
                     float pn, dd;
                     riccati_step<NX, NU, EXACT, H16>(G, is_x, p, lin_cost<EXACT, H16>(cq, rho, tb), pn, dd); // admm.cpp:19-20,80-82
                     c[i] = upd_d ? dd : ci;
@@ -196,7 +195,7 @@ __global__ __launch_bounds__(WAVE, 3) void admm_rowloop_kernel(const RowParams P
             stw<H16>(P.xu, o, sv);
             s = xn;
             const float sni = b[i * WAVE];
-            const float lin = lin_cost<EXACT, H16>(ci * maskx, rho, sni - a[i]);
+            const float lin = lin_cost<EXACT, H16>(cost_term(ci, is_x), rho, sni - a[i]);
             stw<H16>(P.qr, o, (i < N - 1 || is_x) ? lin : 0.f);
             if (i == N - 1) stw<H16>(P.pd, o, is_x ? pN : 0.f);
             else if (cold && !ran_bwd) stw<H16>(P.pd, o, 0.f);

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(WAVE) void admm_step_kernel(const RowParams P, cons
             }
             else
                 xr = ldw<H16>(P.xref, xref_off + i * 16);
-            const float cq = is_x ? rnd<H16>(-(xr * qrow)) : 0.f;
+            const float cq = is_x ? rnd<H16>(-(xr * qrow)) : -0.f; // -0: r = -rho*(znew - y) keeps the sign of a zero difference
             t1 = ldw<H16>(P.vzn, rowbase + i * 16) - ldw<H16>(P.gy, rowbase + i * 16);
             const float lin = lin_cost<EXACT, H16>(cq, rho, t1);
             if (valid) stw<H16>(P.qr, rowbase + i * 16, (i < N - 1 || is_x) ? lin : 0.f);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(WAVE) void admm_rowstream_kernel(const RowParams P)
                 {
                     const int o = rowbase + i * 16;
                     const float sni = ldw<H16>(P.vzn, o);
-                    const float cq = is_x ? rnd<H16>(-(xref_at(i) * qrow)) : 0.f;
+                    const float cq = is_x ? rnd<H16>(-(xref_at(i) * qrow)) : -0.f; // -0: r = -rho*(znew - y) keeps the sign of a zero difference
                     float pn, dd;
                     riccati_step<NX, NU, EXACT, H16>(G, is_x, p, lin_cost<EXACT, H16>(cq, rho, sni - ldw<H16>(P.gy, o)), pn, dd);
                     stw<H16>(P.pd, o, is_u ? dd : pn);
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(WAVE) void admm_rowstream_kernel(const RowParams P)
             else sv = is_x ? s : 0.f;
             if (valid && solved) stw<H16>(P.xu, o, sv);
             s = xn;
-            const float cq = is_x ? rnd<H16>(-(xref_at(i) * qrow)) : 0.f;
+            const float cq = is_x ? rnd<H16>(-(xref_at(i) * qrow)) : -0.f; // -0: r = -rho*(znew - y) keeps the sign of a zero difference
             const float lin = lin_cost<EXACT, H16>(cq, rho, ldw<H16>(P.vzn, o) - ldw<H16>(P.gy, o));
             if (valid) stw<H16>(P.qr, o, (i < N - 1 || is_x) ? lin : 0.f);
         }

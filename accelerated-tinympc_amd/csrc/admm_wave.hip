@@ -111,7 +111,7 @@ __device__ __forceinline__ void wave_lqr_step(const WaveGains<NX, NU> &G, float 
     float acc;
     if constexpr (PL::FWD_U == PL::FWD_XA) acc = wreduce<PL::FWD_XA>(t);
     else acc = is_x ? wreduce<PL::FWD_XA>(t) : wreduce<PL::FWD_U>(t);
-    const float un = acc - ci; // u rows of M1 hold -Kinf: (-(K x)) - d
+    const float un = -acc - ci; // u rows of M1 hold +Kinf: -(K x) - d with the sum negated, like the reference
     float t2[NU];
     lane_products<NX, NU>(t2, un, G.M2, vec, lane);
     xn = acc + wreduce<PL::FWD_XB>(t2);
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(WAVE, 3) void admm_wavestream_kernel(const RowParam
             const int o = rowbase + i * WAVE;
             const float sni = sn_nx, gi = g_nx, xri = xr_nx;
             if (i > 0) { sn_nx = P.vzn[o - WAVE]; g_nx = P.gy[o - WAVE]; xr_nx = xref_at(i - 1); }
-            const float cq = is_x ? -(xri * qrow) : 0.f;
+            const float cq = is_x ? -(xri * qrow) : -0.f; // -0: r = -rho*(znew - y) keeps the sign of a zero difference
             float pn, dd;
             wave_riccati_step<NX, NU>(G, vec, lane, is_x, p, cq - rho * (sni - gi), pn, dd); // admm.cpp:19-20,80-82
             P.pd[o] = is_u ? dd : pn;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(WAVE, 3) void admm_wavestream_kernel(const RowParam
             else sv = is_x ? s : 0.f;
             if (solved) P.xu[o] = sv;
             s = xn;
-            const float cq = is_x ? -(xref_at(i) * qrow) : 0.f;
+            const float cq = is_x ? -(xref_at(i) * qrow) : -0.f; // -0: r = -rho*(znew - y) keeps the sign of a zero difference
             const float lin = cq - rho * (P.vzn[o] - P.gy[o]);
             P.qr[o] = (i < N - 1 || is_x) ? lin : 0.f;
         }

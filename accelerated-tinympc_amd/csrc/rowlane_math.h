@@ -165,7 +165,7 @@ struct RowPlans
 };
 
 // Gain rows of one lane (packed by the host, tinympc_batch.hip: pack_gains):
-//   M1[k]  x rows A(r,k)      | u rows -K(m,k)            M2[m]  x rows B(r,m) | u rows 0
+//   M1[k]  x rows A(r,k)      | u rows K(m,k) (exact) / -K(m,k) (fast)     M2[m]  x rows B(r,m) | u rows 0
 //   M3[k]  x rows AmBKt(r,k)  | u rows  B(k,m)            M45[m] x rows K(m,r) (exact) / -K(m,r) (fast) | u rows Quu_inv(mr,m)
 template <int NX, int NU>
 struct RowGains
@@ -198,7 +198,9 @@ __device__ __forceinline__ void lqr_step(const RowGains<NX, NU> &G, bool is_x, b
         float acc;
         if constexpr (PL::FWD_U == PL::FWD_XA) acc = reduce<PL::FWD_XA>(t);
         else acc = is_x ? reduce<PL::FWD_XA>(t) : reduce<PL::FWD_U>(t);
-        const float un = rnd<H16>(acc - ci); // the u rows of M1 hold -Kinf; negation is exact, so this is (-(K x)) - d bit for bit
+        // u rows of M1 hold +Kinf: the SUM is negated, as in the reference's -(K x) - d.  (Negated gains would give the same
+        // value but the other sign of zero when products of mixed-sign zeros are summed.)
+        const float un = rnd<H16>(-acc - ci);
         float t2[NU];
         dpp_products<NX, NU>(t2, un, G.M2);
         xn = rnd<H16>(acc + reduce<PL::FWD_XB>(t2));
@@ -256,6 +258,14 @@ __device__ __forceinline__ void riccati_step(const RowGains<NX, NU> &G, bool is_
         dpp_fma_acc<NX, NU>(acc, lin, G.M45);             // x rows: -Kinf^T
         pn = rnd<H16>(acc);
     }
+}
+
+// cost term of a step as lin_cost() wants it: x rows keep c = -(Xref.*Q), u rows (where c holds d) get NEGATIVE zero, so that
+// cq - rho*t1 equals the reference's r = -rho*(znew - y) also in the sign of a zero (one v_and_or_b32)
+__device__ __forceinline__ float cost_term(float c, bool is_x)
+{
+    const unsigned keep = is_x ? 0xffffffffu : 0u, set = is_x ? 0u : 0x80000000u;
+    return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, c) & keep) | set);
 }
 
 // [q_i ; r_i] of update_linear_cost (admm.cpp:80-82): cq = -(Xref_i .* Q) on x rows and 0 on u rows, t1 = snew - dual

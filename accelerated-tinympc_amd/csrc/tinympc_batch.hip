@@ -496,7 +496,7 @@ int pack_gains(TinyBatch *tb)
     {
         const int RW = tb->rw;
         // ---- gains for the rowlane kernel: [3nx + 2nu + 1][16], entry (reg, r) = the value lane r of a row holds.
-        //   M1[k]  (k<nx): x rows A(r,k)      | u rows -K(m,k)
+        //   M1[k]  (k<nx): x rows A(r,k)      | u rows K(m,k) (exact: the kernel negates the SUM, like the reference) / -K(m,k) (fast)
         //   M2[m]  (m<nu): x rows B(r,m)      | u rows  0
         //   M3[k]  (k<nx): x rows AmBKt(r,k)  | u rows  B(k,m)          [= Bdyn^T]
         //   M45[m] (m<nu): x rows K(m,r) (exact) / -K(m,r) (fast)  | u rows  Quu_inv(mr,m)
@@ -513,7 +513,7 @@ int pack_gains(TinyBatch *tb)
                 const int mr = r - nx;
                 for (int k = 0; k < nx; k++)
                 {
-                    m[(size_t)k * RW + r] = isx ? Aat(r, k) : (isu ? -Kat(mr, k) : 0.f);
+                    m[(size_t)k * RW + r] = isx ? Aat(r, k) : (isu ? sg * Kat(mr, k) : 0.f); // u rows: K (exact), -K (fast)
                     m[(size_t)(nx + nu + k) * RW + r] = isx ? Amat(r, k) : (isu ? Bat(k, mr) : 0.f);
                     m[(size_t)(2 * nx + 2 * nu + 1 + k) * RW + r] = isx ? Pat(k, r) : 0.f;
                 }

@@ -230,7 +230,8 @@ void SUF(oracle_update_linear_cost)(const SUF(OracleProblem) * P, SUF(OracleWork
     }
 }
 
-static inline REAL SUF(absr)(REAL a) { return a < 0 ? -a : a; }
+/* cwiseAbs clears the sign bit: |-0| = +0 (the sign of a zero residual is observable in the workspace) */
+static inline REAL SUF(absr)(REAL a) { return (REAL)__builtin_fabs((double)a); }
 
 /* src/tinympc/admm.cpp:91-109 */
 int SUF(oracle_termination_condition)(const SUF(OracleProblem) * P, SUF(OracleWork) * W)

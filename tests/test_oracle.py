@@ -72,7 +72,13 @@ def test_oracle_bit_exact_vs_compiled_reference(oracle_mod, tinympc, dt, nx, nu,
     st0 = O.new_state(B, nx, nu, N, dt)
     for k in STATE_ORDER:
         st0[k][:] = (rng.standard_normal(st0[k].shape) * 0.3).astype(dt)
+    # zeros and negative zeros in the live-in state: their signs propagate into products, sums and residuals
+    for k in ("x", "d", "v", "z", "g", "y"):
+        st0[k][rng.random(st0[k].shape) < 0.1] = 0.0
+        st0[k][rng.random(st0[k].shape) < 0.1] = -0.0
+    st0["x"][0, 0] = -0.0; st0["g"][0] = 0.0; st0["y"][0] = 0.0; st0["d"][0] = 0.0   # an instance that sits at the origin
     xref = (rng.standard_normal((B, N, nx)) * 0.2).astype(dt)
+    xref[0] = 0.0
     xmn, xmx, umn, umx = pr.bounds_arrays(prob, dt)
     for settings in (dict(max_iter=1, abs_pri_tol=0, abs_dua_tol=0), dict(max_iter=12, abs_pri_tol=0, abs_dua_tol=0),
                      dict(max_iter=60, check_termination=3), dict(max_iter=5, en_state_bound=0, en_input_bound=0)):
@@ -82,6 +88,8 @@ def test_oracle_bit_exact_vs_compiled_reference(oracle_mod, tinympc, dt, nx, nu,
         assert ra == rb
         for k in STATE_ORDER + ("residuals", "status", "iter"):
             assert np.array_equal(a[k], b[k]), (settings, k)
+            if a[k].dtype.kind == "f":
+                assert np.array_equal(np.signbit(a[k]), np.signbit(b[k])), (settings, k, "sign of a zero")
 
 
 def test_riccati_oracle_vs_reference_codegen(oracle_mod):

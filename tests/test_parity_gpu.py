@@ -59,6 +59,8 @@ def yardstick(O, prob, settings, pre, xref, bnds):
 def assert_bitwise(got, ref, what):
     for k in STATE_ORDER + SCALARS:
         assert np.array_equal(got[k], ref[k]), f"{what}: {k} is not bitwise equal (max diff {np.max(np.abs(got[k].astype(np.float64) - ref[k]))})"
+        if got[k].dtype.kind == "f":  # array_equal treats -0.0 == +0.0: the sign of a zero is part of "bitwise"
+            assert np.array_equal(np.signbit(got[k]), np.signbit(ref[k])), f"{what}: {k} differs in the sign of a zero"
     return 0
 
 
