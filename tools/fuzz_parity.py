@@ -21,7 +21,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 CLASSES = [("quad", 30), ("quad", 25), ("quad", 20), ("quad", 10), ("quad", 17), ("quad", 7), ("quad", 36), ("cartpole", 10),
            ("cartpole", 23), ("odd", 7), ("odd", 13), ("rand32", 50)]
-t_end, rounds, solves, t_note = time.time() + budget, 0, 0, time.time()
+t_end, rounds, solves, t_note, overflowed = time.time() + budget, 0, 0, time.time(), 0
 while time.time() < t_end:
     if time.time() - t_note > 30:
         print(f"... {rounds} rounds, {solves} solves so far", flush=True)
@@ -42,7 +42,12 @@ while time.time() < t_end:
         xmx[rng.integers(N), rng.integers(nx)] = np.inf
         xmn[rng.integers(N), rng.integers(nx)] = -np.inf
     bnds = (xmn, xmx, umn, umx)
+    bnds_raw = bnds
     sol = T.TinyBatchSolver(prob, B, settings=settings)
+    h16 = kind != "rand32" and rng.random() < 0.3   # fp16 storage / fp32 arithmetic against the oracle's _h16 restatement
+    if h16:
+        sol.set_storage(16)
+    R = O.round_h16 if h16 else (lambda a: a)
     fams = [0] + ([f for f in (1, 2, 3, 4) if kind != "rand32"])
     fam = int(rng.choice(fams))
     try:
@@ -50,6 +55,7 @@ while time.time() < t_end:
     except T.TinyBatchError:
         sol.set_row_kernel(0)
     sol.set_bounds(*bnds)
+    bnds = tuple(R(b) for b in bnds)
     mode = rng.integers(3) if nx <= 16 else rng.integers(2)
     if mode == 0:
         xref = (rng.standard_normal((N, nx)) * 0.3).astype(np.float32); sol.set_xref(xref)
@@ -59,32 +65,56 @@ while time.time() < t_end:
         table = (rng.standard_normal((N + 40, nx)) * 0.3).astype(np.float32)
         start = rng.integers(0, 40, size=B).astype(np.int32)
         sol.set_xref_window(table, start); xref = pr.expand_windows(table, start, N)
+    xref = R(xref)
     st = O.new_state(B, nx, nu, N)
     if rng.random() < 0.7:   # warm workspace, sprinkled with zeros and negative zeros
         for k in O.STATE_ORDER:
             v = (rng.standard_normal(st[k].shape) * 0.3).astype(np.float32)
             v[rng.random(v.shape) < 0.1] = 0.0
             v[rng.random(v.shape) < 0.05] = -0.0
-            st[k][:] = v
+            st[k][:] = R(v)
         st["residuals"][:] = rng.uniform(0, 1, size=(B, 4)).astype(np.float32)
         st["iter"][:] = rng.integers(1, 9, size=B); st["status"][:] = 11
         sol.set_state(st)
     else:
         x0 = rng.uniform(-0.5, 0.5, size=(B, nx)).astype(np.float32)
-        st["x"][:, 0] = x0; sol.set_x0(x0)
-    orc = O.Oracle(prob, np.float32, settings)
+        st["x"][:, 0] = R(x0); sol.set_x0(x0)
+    orc = O.Oracle(prob, "h16" if h16 else np.float32, settings)
     for k in range(int(rng.integers(1, 4))):
         if rng.random() < 0.6:
             st["y"][:] = 0; st["g"][:] = 0; sol.reset_dual_variables()
         orc.solve(st, *bnds, xref, nthreads=8); sol.solve(); solves += 1
+        if not all(np.all(np.isfinite(st[n_])) for n_ in O.STATE_ORDER):
+            overflowed += 1   # NaN / inf regime (fp16 storage overflow, unstable iteration): behaviour undefined
+            break
         got = sol.get_state()
         for name in O.STATE_ORDER + ("residuals", "status", "iter"):
-            if not np.array_equal(got[name], st[name]) or (got[name].dtype == np.float32 and not np.array_equal(np.signbit(got[name]), np.signbit(st[name]))):
-                print(f"MISMATCH round {rounds} {kind} N={N} B={B} kernel {sol.kernel_name()} settings {settings} xref mode {mode} solve {k}: {name}")
+            g_, r_ = got[name], st[name]
+            if g_.dtype == np.float32:   # NaN (overflowing fp16 storage, inf - inf) only has to be NaN on both sides
+                nn = np.isnan(g_) & np.isnan(r_)
+                same = np.all((g_ == r_) | nn) and np.array_equal(np.signbit(g_)[~nn], np.signbit(r_)[~nn])
+            else:
+                same = np.array_equal(g_, r_)
+            if not same:
+                print(f"MISMATCH round {rounds} h16={h16} {kind} N={N} B={B} kernel {sol.kernel_name()} settings {settings} xref mode {mode} solve {k}: {name}")
                 bad = np.argwhere(~((got[name] == st[name]) & (np.signbit(got[name]) == np.signbit(st[name]))))
                 for idx in bad[:6]:
                     idx = tuple(idx)
                     print("   ", idx, "gpu", got[name][idx], "oracle", st[name][idx], "iter gpu/oracle", got["iter"][idx[0]], st["iter"][idx[0]])
                 sys.exit(1)
+    finite = all(np.all(np.isfinite(st[n_])) for n_ in O.STATE_ORDER)
+    if finite and nx + nu <= 16 and rng.random() < 0.3:   # one of the six step functions on the state the chain left
+        fn = O.Oracle.STEP_FUNCTIONS[rng.integers(6)]
+        ref_rv = orc.step(fn, st, *bnds, xref)
+        rv = getattr(sol, fn)()
+        got = sol.get_state()
+        ok = fn != "termination_condition" or np.array_equal(rv, ref_rv)
+        for name in O.STATE_ORDER + ("residuals",):
+            nn = np.isnan(got[name]) & np.isnan(st[name])
+            ok = ok and np.all((got[name] == st[name]) | nn) and np.array_equal(np.signbit(got[name])[~nn], np.signbit(st[name])[~nn])
+        if not ok:
+            print(f"MISMATCH round {rounds} step function {fn} {kind} N={N} B={B} h16={h16} settings {settings}")
+            sys.exit(1)
     sol.close(); rounds += 1
-print(f"fuzz ok: {rounds} rounds, {solves} solves, all bitwise equal to the oracle (signs of zeros included)")
+print(f"fuzz ok: {rounds} rounds, {solves} solves, all bitwise equal to the oracle (signs of zeros included); "
+      f"{overflowed} rounds left the finite range and were not compared")
