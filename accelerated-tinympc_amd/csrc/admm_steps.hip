@@ -39,7 +39,7 @@ __global__ __launch_bounds__(WAVE) void admm_step_kernel(const RowParams P, cons
     {
         for (int i = 0; i < N; i++)
         {
-            const float2 lh = ld_bounds<H16>(P.bounds, i * 16 + r16);
+            const float2 lh = ld_bounds<H16>(P.bounds, inst * (int)P.bounds_inst_stride + i * 16 + r16);
             const float t = ldw<H16>(P.xu, rowbase + i * 16) + ldw<H16>(P.gy, rowbase + i * 16);
             if (valid) stw<H16>(P.vzn, rowbase + i * 16, __builtin_amdgcn_fmed3f(t, lh.x, lh.y));
         }
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(WAVE) void admm_rowstream_kernel(const RowParams P)
                 float sv, xn = 0.f;
                 if (i < N - 1) lqr_step<NX, NU, EXACT, H16>(G, is_x, is_u, s, zero_state ? 0.f : ldw<H16>(P.pd, o), sv, xn);
                 else sv = is_x ? s : 0.f;
-                const float2 lh = ld_bounds<H16>(P.bounds, i * 16 + r16);
+                const float2 lh = ld_bounds<H16>(P.bounds, inst * (int)P.bounds_inst_stride + i * 16 + r16);
                 const float a = zero_duals ? 0.f : ldw<H16>(P.gy, o);
                 const float bprev = zero_state ? 0.f : ldw<H16>(P.vz, o);
                 const float t = __builtin_amdgcn_fmed3f(rnd<H16>(sv + a), lh.x, lh.y);

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(WAVE, 3) void admm_wavestream_kernel(const RowParam
     const int N = P.N;
     const int rowbase = (inst * N) * WAVE + lane;
     const float rho = P.rho;
-    const float2 *bnd = reinterpret_cast<const float2 *>(P.bounds);
+    const float2 *bnd = reinterpret_cast<const float2 *>(P.bounds) + (size_t)inst * P.bounds_inst_stride; // shared or per instance
     WaveGains<NX, NU> G;
     G.load(P.mats, lane);
     const float qrow = P.mats[(2 * NX + 2 * NU) * WAVE + lane];

@@ -164,6 +164,40 @@ __global__ void plant_step_kernel(float *__restrict__ x0buf, float *__restrict__
     if (wstart && window_advance) wstart[b] += window_advance;
 }
 
+// per-instance bounds table of the ROW layout: dst[b][step][r] = {min(lo, hi), hi}, +-inf where a bound is disabled or the
+// row carries nothing.  Sources are the canonical inputs ([B or 1][steps][dim], NULL = not set = 0).
+__global__ void bounds_table_kernel(const float *__restrict__ xmin, const float *__restrict__ xmax, const float *__restrict__ umin,
+                                    const float *__restrict__ umax, int sh_x, int sh_u, float *__restrict__ dst, Geo g, int nb,
+                                    int en_state, int en_input, int h16)
+{
+    const long long total = (long long)nb * g.N * g.rw;
+    const float inf = __builtin_inff();
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x)
+    {
+        const int r = (int)(e % g.rw);
+        const long long t = e / g.rw;
+        const int i = (int)(t % g.N), b = (int)(t / g.N);
+        float lo = -inf, hi = inf;
+        if (r < g.nx && en_state)
+        {
+            const long long o = ((long long)(sh_x ? 0 : b) * g.N + i) * g.nx + r;
+            lo = xmin ? xmin[o] : 0.f; hi = xmax ? xmax[o] : 0.f;
+        }
+        else if (r >= g.nx && r < g.nx + g.nu && i < g.N - 1 && en_input)
+        {
+            const long long o = ((long long)(sh_u ? 0 : b) * (g.N - 1) + i) * g.nu + (r - g.nx);
+            lo = umin ? umin[o] : 0.f; hi = umax ? umax[o] : 0.f;
+        }
+        lo = lo < hi ? lo : hi;
+        if (h16)
+        {
+            reinterpret_cast<_Float16 *>(dst)[2 * e] = (_Float16)lo;
+            reinterpret_cast<_Float16 *>(dst)[2 * e + 1] = (_Float16)hi;
+        }
+        else { dst[2 * e] = lo; dst[2 * e + 1] = hi; }
+    }
+}
+
 int grid_for(long long total, int block = 256)
 {
     long long gsz = (total + block - 1) / block;
@@ -562,6 +596,21 @@ int prepare_inputs(TinyBatch *tb, int layout)
         // (min(hi, max(lo, t)) == med3(t, min(lo,hi), hi) for every t, also for the infeasible lo > hi case)
         const float inf = std::numeric_limits<float>::infinity();
         const int RW = tb->rw;
+        if (!bounds_all_shared(tb)) // per-instance bounds: [bpad4][N][rw]{lo,hi}, built on the device from the canonical inputs
+        {
+            const size_t nf = (size_t)tb->bpad4 * N * RW * 2;
+            if (tb->r_bounds) { (void)hipFree(tb->r_bounds); tb->r_bounds = nullptr; }
+            TRY(dev_alloc_zero(&tb->r_bounds, tb->h16 ? (nf + 1) / 2 : nf));
+            const InputArr *in = tb->in_bnd;
+            hipLaunchKernelGGL(bounds_table_kernel, dim3(grid_for((long long)tb->batch * N * RW)), dim3(256), 0, tb->stream,
+                               in[0].set ? in[0].dev : nullptr, in[1].set ? in[1].dev : nullptr, in[2].set ? in[2].dev : nullptr,
+                               in[3].set ? in[3].dev : nullptr, (in[0].set ? in[0].shared : in[1].shared) ? 1 : 0,
+                               (in[2].set ? in[2].shared : in[3].shared) ? 1 : 0, tb->r_bounds, geo(tb), tb->batch, tb->en_state_bound,
+                               tb->en_input_bound, tb->h16 ? 1 : 0);
+            HIP_TRY(hipGetLastError());
+        }
+        else
+        {
         std::vector<float> tab((size_t)N * RW * 2);
         for (int i = 0; i < N; i++)
             for (int r = 0; r < RW; r++)
@@ -594,6 +643,7 @@ int prepare_inputs(TinyBatch *tb, int layout)
             if (tb->r_bounds) { (void)hipFree(tb->r_bounds); tb->r_bounds = nullptr; }
             TRY(upload_vec(tb, &tb->r_bounds, tab));
         }
+        }
         const size_t nf = (size_t)(tb->in_xref.set && !tb->in_xref.shared ? tb->bpad4 : 1) * N * RW;
         if (tb->r_xref) { (void)hipFree(tb->r_xref); tb->r_xref = nullptr; }
         TRY(dev_alloc_zero(&tb->r_xref, tb->h16 ? (nf + 1) / 2 : nf));
@@ -609,20 +659,20 @@ int resolve_variant(TinyBatch *tb, int *out)
 {
     int v = tb->variant;
     // row variants: register-resident kernel when (nx,nu,N) is instantiated, else the any-N row kernel with the state in HBM
-    const bool row_ok = (tb->row_dims_ok || tb->rowmath_ok || tb->wave_ok) && bounds_all_shared(tb);
+    // per-instance bounds: the streaming row kernel and the wave kernel read them per instance; the register-resident
+    // kernels stage ONE table in LDS and need batch-shared bounds
+    const bool row_ok = tb->row_dims_ok || tb->rowmath_ok || tb->wave_ok;
     if (tb->variant == VAR_ROW_FAST && tb->wave_ok)
         return fail(TINY_BATCH_EUNSUPPORTED, "the wave-per-instance kernel (16 < nx + nu <= 64) has exact arithmetic only; fma arithmetic for these sizes is the streaming MFMA kernel (variant 1)");
     if (v == VAR_AUTO) v = row_ok ? VAR_ROW_EXACT : VAR_STREAM;
     if ((v == VAR_ROW_EXACT || v == VAR_ROW_FAST) && !row_ok)
     {
-        if (tb->row_dims_ok || tb->rowmath_ok || tb->wave_ok)
-            return fail(TINY_BATCH_EUNSUPPORTED, "the row kernels need batch-shared bounds; per-instance bounds run on the streaming kernel");
         return fail(TINY_BATCH_EUNSUPPORTED, "no row kernel instantiation for nx=%d nu=%d (needs nx + nu <= 16)", tb->nx, tb->nu);
     }
     if (v == VAR_STREAM && !tb->tile_dims_ok)
         return fail(TINY_BATCH_EUNSUPPORTED, "no streaming kernel instantiation for nx=%d nu=%d", tb->nx, tb->nu);
     if (v == VAR_STREAM && tb->h16)
-        return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage is implemented by the row kernels only (nx + nu <= 16, batch-shared bounds)");
+        return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage is implemented by the row kernels only (nx + nu <= 16)");
     *out = v;
     return 0;
 }
@@ -633,6 +683,7 @@ int resolve_variant(TinyBatch *tb, int *out)
 int row_family(const TinyBatch *tb)
 {
     if (tb->wave_ok) return 3; // one wavefront per instance, state in HBM (admm_wave.hip)
+    if (!bounds_all_shared(tb)) return 2; // per-instance bounds: only the streaming row kernel reads them per instance
     if (tb->row_family_forced >= 0) return tb->row_family_forced;
     if (tb->quad_ok) return 4; // four lanes per instance (admm_quadlane.hip): nx = 4, nu = 1
     if (tb->row_dims_ok) return 0;
@@ -669,6 +720,7 @@ void fill_row_params(TinyBatch *tb, RowParams &P, bool exact)
     P.xref_inst_stride = (tb->in_xref.set && !tb->in_xref.shared) ? (unsigned)(tb->N * tb->rw) : 0u;
     P.xref_table = tb->h16 ? tb->tab_row_h : tb->tab_row; P.xref_start = tb->xref_start; P.table_rows = tb->table_rows;
     P.bounds = tb->r_bounds;
+    P.bounds_inst_stride = bounds_all_shared(tb) ? 0u : (unsigned)(tb->N * tb->rw);
     P.mats = exact ? tb->mats_exact : tb->mats_fast;
     P.res = tb->res; P.status = tb->status; P.iter = tb->iter; P.n_unsolved = tb->n_unsolved;
     P.mpc_steps = 1; P.window_advance = 0; P.u0_traj = nullptr; P.x0buf = tb->x0buf;
@@ -681,8 +733,6 @@ int run_step(TinyBatch *tb, int fn, int *converged_host, int *n_true)
         return fail(TINY_BATCH_ENOTREADY, "set_cache, set_dynamics and set_settings must be called first");
     if (!tb->rowmath_ok)
         return fail(TINY_BATCH_EUNSUPPORTED, "the single-function kernels need nx + nu <= 16 and an entry in TINY_FOR_EACH_ROWDIMS (nx=%d nu=%d)", tb->nx, tb->nu);
-    if (fn == STEP_UPDATE_SLACK && !bounds_all_shared(tb))
-        return fail(TINY_BATCH_EUNSUPPORTED, "update_slack as a separate call needs batch-shared bounds");
     TRY(set_device(tb));
     if (tb->gains_dirty) TRY(pack_gains(tb));
     TRY(ensure_layout(tb, LAYOUT_ROW));

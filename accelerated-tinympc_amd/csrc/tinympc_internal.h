@@ -91,7 +91,9 @@ struct RowParams
     const float *xref_table;     // [rows][16]
     int *xref_start;             // [batch] window start; advanced by the closed-loop kernels
     int table_rows;
-    const float *bounds;         // [N][16][2] = {lo, hi}; +-inf where a bound is disabled or the row is unused
+    const float *bounds;         // [N][rw][2] = {lo, hi}; +-inf where a bound is disabled or the row is unused
+    unsigned bounds_inst_stride; // {lo,hi} entries between instances: 0 = one table for the batch, N*rw = per-instance bounds
+                                 // (streaming row kernel, step kernels and wave kernel only)
     const float *mats;           // [3nx + 2nu + 1][16] gain rows per lane (see pack_row_mats)
     float *res;
     int *status, *iter, *n_unsolved;

@@ -222,17 +222,11 @@ def test_settings_variants_vs_oracle(tinympc, oracle_mod, variant):
     for over, bnds in variants:
         settings = dict(O.DEFAULT_SETTINGS, **over)
         orc = O.Oracle(prob, np.float32, settings)
-        if bnds[0].ndim == 3 and variant != "stream":
-            # per-instance bounds are served by the streaming kernel: a forced rowlane variant must refuse loudly,
-            # and the automatic choice must fall back
-            sol = make_solver(tinympc, prob, B, settings, xref, variant, bnds)
-            with pytest.raises(tinympc.TinyBatchError):
-                sol.solve()
-            sol.select_kernel(0)
-            assert sol.kernel_name().startswith("stream")
-            sol.close()
-            continue
         sol = make_solver(tinympc, prob, B, settings, xref, variant, bnds)
+        if bnds[0].ndim == 3 and variant != "stream":
+            # per-instance bounds: the register-resident kernels stage ONE bounds table in LDS, so every row variant runs
+            # on the streaming row kernel, which reads the bounds per instance (same arithmetic: still bitwise when exact)
+            assert sol.kernel_name().startswith("rowstream"), sol.kernel_name()
         st = O.new_state(B, 12, 4, 30)
         st["x"][:, 0] = x0
         st["residuals"][:] = rng.uniform(0, 1, size=(B, 4)).astype(np.float32)  # residual fields are live-in
@@ -1095,3 +1089,36 @@ def test_kernel_selection_and_option_errors(tinympc):
         tinympc.solve_group([a, a])                                # the same handle twice
     assert tinympc.solve_group([a]) >= 0                           # a group of one is an ordinary solve
     a.close()
+
+
+def test_per_instance_bounds_exact(tinympc, oracle_mod):
+    """Per-instance (and per-step) box bounds in exact arithmetic: quadrotor on the streaming row kernel, the nx = 32 class on
+    the wave kernel, and update_slack as a separate call — all bitwise equal to the oracle; fp16 storage too."""
+    O, pr = oracle_mod, tinympc.problems
+    for prob, B, name in ((pr.quadrotor(20, 30), 37, "rowstream"), (pr.random_system(32, 16, 50), 5, "wavestream")):
+        nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+        rng = np.random.default_rng(B)
+        x0 = rng.uniform(-0.4, 0.4, size=(B, nx)).astype(np.float32)
+        xref = (rng.standard_normal((N, nx)) * 0.1).astype(np.float32)
+        bnds = tuple((a[None] * rng.uniform(0.05, 1.0, size=(B,) + a.shape)).astype(np.float32) for a in pr.bounds_arrays(prob))
+        settings = dict(O.DEFAULT_SETTINGS, max_iter=25, check_termination=2)
+        for storage in ((32, 16) if name == "rowstream" else (32,)):
+            sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+            sol.set_storage(storage)
+            sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
+            assert sol.kernel_name().startswith(name), sol.kernel_name()
+            R = O.round_h16 if storage == 16 else (lambda a: a)
+            orc = O.Oracle(prob, "h16" if storage == 16 else np.float32, settings)
+            st = O.new_state(B, nx, nu, N); st["x"][:, 0] = R(x0)
+            bn = tuple(R(b) for b in bnds)
+            for k in range(2):
+                st["y"][:] = 0; st["g"][:] = 0
+                sol.reset_dual_variables()
+                orc.solve(st, *bn, R(xref), nthreads=8)
+                sol.solve()
+                assert_bitwise(sol.get_state(), st, f"per-instance bounds {sol.kernel_name()} k={k}")
+            if name == "rowstream":
+                orc.step("update_slack", st, *bn, R(xref))
+                sol.update_slack()
+                assert_bitwise(sol.get_state(), st, "update_slack with per-instance bounds")
+            sol.close()
