@@ -42,6 +42,8 @@ while time.time() < t_end:
         xmx[rng.integers(N), rng.integers(nx)] = np.inf
         xmn[rng.integers(N), rng.integers(nx)] = -np.inf
     bnds = (xmn, xmx, umn, umx)
+    if rng.random() < 0.25:  # per-instance bounds (served by the kernels that stream their state)
+        bnds = tuple((a[None] * rng.uniform(0.3, 1.0, size=(B,) + a.shape)).astype(np.float32) for a in bnds)
     bnds_raw = bnds
     sol = T.TinyBatchSolver(prob, B, settings=settings)
     h16 = kind != "rand32" and rng.random() < 0.3   # fp16 storage / fp32 arithmetic against the oracle's _h16 restatement
