@@ -1122,3 +1122,32 @@ def test_per_instance_bounds_exact(tinympc, oracle_mod):
                 sol.update_slack()
                 assert_bitwise(sol.get_state(), st, "update_slack with per-instance bounds")
             sol.close()
+
+
+@pytest.mark.parametrize("variant_name", ["row_exact", "loop_exact", "rowstream_exact", "lane_exact", "stream"])
+def test_cold_start_that_converges_immediately(tinympc, oracle_mod, variant_name):
+    """reset_workspace() then a solve from x0 = 0 with a zero reference converges in its first iteration, before any backward
+    sweep: p, d, v, z must read back as the zeros reset_workspace() promised (not whatever an earlier solve left in memory),
+    and x, u follow from d = 0.  Found by tools/fuzz_api.py on the kernels that stream their state."""
+    O, pr = oracle_mod, tinympc.problems
+    for prob in (pr.quadrotor(20, 30), pr.cartpole(10), pr.random_system(32, 16, 50)):
+        nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+        B = 9
+        rng = np.random.default_rng(1)
+        bnds = pr.bounds_arrays(prob)
+        try:
+            sol = make_solver(tinympc, prob, B, dict(O.DEFAULT_SETTINGS, max_iter=30), None, variant_name, bnds)
+        except pytest.skip.Exception:
+            continue
+        # dirty the workspace with an ordinary solve first
+        sol.set_xref((rng.standard_normal((N, nx)) * 0.2).astype(np.float32))
+        sol.set_x0(rng.uniform(-0.3, 0.3, size=(B, nx)).astype(np.float32))
+        sol.solve()
+        sol.set_xref(np.zeros((N, nx), np.float32))
+        sol.reset_workspace()                      # x0 stays 0
+        sol.solve()
+        got = sol.get_state()
+        assert np.all(got["iter"] == 1) and np.all(got["status"] == 1)
+        for name in STATE_ORDER:
+            assert not np.any(got[name]), f"{sol.kernel_name()}: {name} is not zero after a trivially converged cold start"
+        sol.close()
