@@ -41,15 +41,18 @@ while time.time() < t_end:
     bnds = pr.bounds_arrays(prob)
     xref = (rng.standard_normal((B, N, nx)) * 0.2).astype(np.float32)
     sol.set_bounds(*bnds); sol.set_xref(xref)
+    h16 = False
+    R = lambda a: a
     orc = O.Oracle(prob, np.float32, settings)
     st = O.new_state(B, nx, nu, N)
     history = []
     for _ in range(int(rng.integers(4, 14))):
-        op = rng.choice(["set_x0", "reset_dual", "reset_ws", "set_array", "set_status", "switch", "solve", "solve", "read", "get_array"])
+        op = rng.choice(["set_x0", "reset_dual", "reset_ws", "set_array", "set_status", "switch", "solve", "solve", "read", "get_array",
+                         "storage", "bounds", "xref"])
         history.append(str(op)); ops_done += 1
         if op == "set_x0":
             x0 = rng.uniform(-0.5, 0.5, size=(B, nx)).astype(np.float32)
-            sol.set_x0(x0); st["x"][:, 0] = x0
+            sol.set_x0(x0); st["x"][:, 0] = R(x0)
         elif op == "reset_dual":
             sol.reset_dual_variables(); st["y"][:] = 0; st["g"][:] = 0
         elif op == "reset_ws":
@@ -59,7 +62,7 @@ while time.time() < t_end:
         elif op == "set_array":
             name = O.STATE_ORDER[rng.integers(12)]
             v = (rng.standard_normal(st[name].shape) * 0.2).astype(np.float32)
-            sol.set_array(name, v); st[name][:] = v
+            sol.set_array(name, v); st[name][:] = R(v)
         elif op == "set_status":
             st["iter"][:] = rng.integers(1, 9, size=B); st["status"][:] = rng.choice([1, 11], size=B)
             st["residuals"][:] = rng.uniform(0, 1, size=(B, 4)).astype(np.float32)
@@ -76,12 +79,38 @@ while time.time() < t_end:
         elif op == "solve":
             if sol.kernel_name().startswith("stream"):
                 sol.select_kernel(2)  # only exact arithmetic can be mirrored bit for bit
-            orc.solve(st, *bnds, xref, nthreads=4); sol.solve()
+            orc.solve(st, *[R(b_) for b_ in bnds], R(xref), nthreads=4); sol.solve()
             if not all(np.all(np.isfinite(st[n_])) for n_ in O.STATE_ORDER):
                 break
             check(sol, st, "solve")
         elif op == "read":
             check(sol, st, "read")
+        elif op == "storage":   # switching the storage precision restarts the workspace from zero (like create)
+            if sol.kernel_name().startswith("stream"):
+                sol.select_kernel(2)
+            h16 = not h16
+            sol.set_storage(16 if h16 else 32)
+            R = O.round_h16 if h16 else (lambda a: a)
+            orc = O.Oracle(prob, "h16" if h16 else np.float32, settings)
+            for k in O.STATE_ORDER + ("residuals", "status", "iter"):
+                st[k][:] = 0
+            history[-1] = f"storage->{16 if h16 else 32}"
+        elif op == "bounds":
+            sc = rng.uniform(0.2, 1.0)
+            bnds = tuple((a * sc).astype(np.float32) for a in pr.bounds_arrays(prob))
+            if rng.random() < 0.3:
+                bnds = tuple((a[None] * rng.uniform(0.5, 1.0, size=(B,) + a.shape)).astype(np.float32) for a in bnds)
+            sol.set_bounds(*bnds)
+        elif op == "xref":
+            m = rng.integers(3)
+            if m == 0:
+                xref = (rng.standard_normal((N, nx)) * 0.2).astype(np.float32); sol.set_xref(xref)
+            elif m == 1:
+                xref = (rng.standard_normal((B, N, nx)) * 0.2).astype(np.float32); sol.set_xref(xref)
+            else:
+                table = (rng.standard_normal((N + 20, nx)) * 0.2).astype(np.float32)
+                start = rng.integers(0, 20, size=B).astype(np.int32)
+                sol.set_xref_window(table, start); xref = pr.expand_windows(table, start, N)
         else:
             name = O.STATE_ORDER[rng.integers(12)]
             g_ = sol.get_array(name)
