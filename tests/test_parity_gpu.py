@@ -1151,3 +1151,15 @@ def test_cold_start_that_converges_immediately(tinympc, oracle_mod, variant_name
         for name in STATE_ORDER:
             assert not np.any(got[name]), f"{sol.kernel_name()}: {name} is not zero after a trivially converged cold start"
         sol.close()
+
+
+@pytest.mark.parametrize("tool", ["fuzz_parity.py", "fuzz_mpc.py", "fuzz_api.py", "fuzz_native.py", "fuzz_fast_families.py"])
+def test_randomised_differential_tools_short_run(tool):
+    """A few seconds of each randomised differential tool (tools/fuzz_*.py; the minutes-long runs are recorded in DESIGN.md),
+    with a fixed seed so that the test is reproducible: keeps the tools working and replays a few thousand drawn cases."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "tools" / tool), "6", "1"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
