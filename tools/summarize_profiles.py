@@ -65,8 +65,8 @@ table = json.loads(tf.read_text()) if tf.exists() else {}
 table = {k: v for k, v in table.items() if not k.startswith("void ")}
 def label(kname):
     import re
-    m = re.search(r"admm_rowlane_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)>", kname)
-    if m:
+    m = re.search(r"admm_rowlane_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)(?:, (true|false))?>", kname)
+    if m and m.group(6) != "true":   # the closed-loop (MPC) instantiation is a different workload
         return f"rowlane<{m.group(1)},{m.group(2)},{m.group(3)},{'exact' if m.group(4) == 'true' else 'fast'}{',h16' if m.group(5) == 'true' else ''}>"
     m = re.search(r"admm_stream_kernel<(\d+), (\d+)>", kname)
     return f"stream<{m.group(1)},{m.group(2)}>" if m else kname
