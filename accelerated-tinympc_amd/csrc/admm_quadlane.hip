@@ -97,10 +97,13 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
     // per-instance state, all in registers: duals a, reference cost term / feed-forward, previous and current slack
     float ax[N], ay[N], cq[N], dd[N], bx[N], bz[N], sx[N], sz[N];
     float pp[N], dl[N]; // [p_i ; d_i] of the last executed backward sweep (live-out only; the live-in values until then)
-    const int rowx = (inst * N) * 16 + j, rowu = (inst * N) * 16 + NX;
+    // 16 instances per wave but the arrays are padded to a multiple of 4 instances only: the quads beyond the batch read
+    // the last instance's rows (and store nothing)
+    const int inst_a = valid ? inst : P.batch - 1;
+    const int rowx = (inst_a * N) * 16 + j, rowu = (inst_a * N) * 16 + NX;
     int wstart = 0;
     if (P.xref_mode == 1 && valid) wstart = P.xref_start[inst];
-    const int xref_off = inst * (int)P.xref_inst_stride + j;
+    const int xref_off = inst_a * (int)P.xref_inst_stride + j;
     const bool cold = P.cold_start != 0;
     const bool zdual = cold || (P.duals_zero != 0);
     float xrN = 0.f;
