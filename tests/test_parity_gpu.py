@@ -1153,7 +1153,8 @@ def test_cold_start_that_converges_immediately(tinympc, oracle_mod, variant_name
         sol.close()
 
 
-@pytest.mark.parametrize("tool", ["fuzz_parity.py", "fuzz_mpc.py", "fuzz_api.py", "fuzz_native.py", "fuzz_fast_families.py"])
+@pytest.mark.parametrize("tool", ["fuzz_parity.py", "fuzz_mpc.py", "fuzz_api.py", "fuzz_native.py", "fuzz_fast_families.py",
+                                  "fuzz_stream_consistency.py"])
 def test_randomised_differential_tools_short_run(tool):
     """A few seconds of each randomised differential tool (tools/fuzz_*.py; the minutes-long runs are recorded in DESIGN.md),
     with a fixed seed so that the test is reproducible: keeps the tools working and replays a few thousand drawn cases."""
