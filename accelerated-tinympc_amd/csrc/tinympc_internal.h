@@ -105,7 +105,7 @@ struct RowParams
 };
 
 // (nx, nu) pairs with single-function kernels (admm_steps.hip), any N
-#define TINY_FOR_EACH_ROWDIMS(X) X(12, 4) X(4, 1) X(8, 3)
+#define TINY_FOR_EACH_ROWDIMS(X) X(12, 4) X(4, 1) X(8, 3) X(8, 4) X(12, 2) X(4, 2) X(4, 4)
 enum { STEP_FORWARD_PASS = 0, STEP_UPDATE_SLACK, STEP_UPDATE_DUAL, STEP_UPDATE_LINEAR_COST, STEP_TERMINATION_CONDITION,
        STEP_BACKWARD_PASS_GRAD };
 

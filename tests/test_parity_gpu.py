@@ -513,7 +513,8 @@ def test_step_functions_individually(tinympc, oracle_mod, case, exact):
 
 
 @pytest.mark.parametrize("case", [("quad", 5), ("quad", 17), ("quad", 20), ("quad", 25), ("quad", 32), ("quad", 33), ("quad", 45),
-                                  ("cartpole", 25), ("cartpole", 40), ("odd", 12), ("odd", 2)])
+                                  ("cartpole", 25), ("cartpole", 40), ("odd", 12), ("odd", 2),
+                                  ("r8_4", 9), ("r8_4", 40), ("r12_2", 11), ("r4_2", 8), ("r4_4", 6)])  # classes pinned in test_oracle.py
 @pytest.mark.parametrize("variant_name", ["row_exact", "row_fast"])
 def test_any_horizon_row_kernel(tinympc, oracle_mod, case, variant_name):
     """Horizons other than the examples' 10 and 30: a few have an unrolled instantiation (rowlane), otherwise N <= 32 runs on
@@ -523,8 +524,12 @@ def test_any_horizon_row_kernel(tinympc, oracle_mod, case, variant_name):
     O, pr = oracle_mod, tinympc.problems
     exact = VARIANTS[variant_name][1]
     kind, N = case
-    prob = {"quad": lambda: pr.quadrotor(20, N), "cartpole": lambda: pr.cartpole(N),
-            "odd": lambda: pr.random_system(8, 3, N, seed=99)}[kind]()
+    if kind.startswith("r") and "_" in kind:
+        nxk, nuk = (int(v) for v in kind[1:].split("_"))
+        prob = pr.random_system(nxk, nuk, N, seed=nxk * 100 + nuk)
+    else:
+        prob = {"quad": lambda: pr.quadrotor(20, N), "cartpole": lambda: pr.cartpole(N),
+                "odd": lambda: pr.random_system(8, 3, N, seed=99)}[kind]()
     nx, nu = prob["nx"], prob["nu"]
     B = 70
     rng = np.random.default_rng(N)

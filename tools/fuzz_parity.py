@@ -20,15 +20,18 @@ pr = T.problems
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 CLASSES = [("quad", 30), ("quad", 25), ("quad", 20), ("quad", 10), ("quad", 17), ("quad", 7), ("quad", 36), ("cartpole", 10),
-           ("cartpole", 23), ("odd", 7), ("odd", 13), ("rand32", 50)]
+           ("cartpole", 23), ("odd", 7), ("odd", 13), ("rand32", 50), ("r8_4", 9), ("r12_2", 14), ("r4_2", 8), ("r4_4", 35)]
 t_end, rounds, solves, t_note, overflowed = time.time() + budget, 0, 0, time.time(), 0
 while time.time() < t_end:
     if time.time() - t_note > 30:
         print(f"... {rounds} rounds, {solves} solves so far", flush=True)
         t_note = time.time()
     kind, N = CLASSES[rng.integers(len(CLASSES))]
-    prob = {"quad": lambda: pr.quadrotor(20, N), "cartpole": lambda: pr.cartpole(N), "odd": lambda: pr.random_system(8, 3, N, seed=99),
-            "rand32": lambda: pr.random_system(32, 16, N)}[kind]()
+    if "_" in kind:
+        prob = pr.random_system(int(kind[1:].split("_")[0]), int(kind.split("_")[1]), N, seed=7)
+    else:
+        prob = {"quad": lambda: pr.quadrotor(20, N), "cartpole": lambda: pr.cartpole(N), "odd": lambda: pr.random_system(8, 3, N, seed=99),
+                "rand32": lambda: pr.random_system(32, 16, N)}[kind]()
     nx, nu = prob["nx"], prob["nu"]
     B = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 200])) if kind != "rand32" else int(rng.choice([1, 3, 9]))
     settings = dict(abs_pri_tol=float(rng.choice([0.0, 1e-3, 1e-2, 0.5])), abs_dua_tol=float(rng.choice([0.0, 1e-3, 1e-1, 5.0])),
