@@ -127,7 +127,7 @@ bool quadlane_supported(int nx, int nu, int N);
 hipError_t launch_admm_quadlane(int N, bool exact, bool h16, const RowParams &P, hipStream_t stream);
 
 // wave-per-instance exact kernel (admm_wave.hip): 16 < nx + nu <= 64, any N, state in HBM, row width 64
-#define TINY_FOR_EACH_WAVEDIMS(X) X(32, 16)
+#define TINY_FOR_EACH_WAVEDIMS(X) X(32, 16) X(16, 8) X(16, 4)
 bool wavedims_supported(int nx, int nu);
 hipError_t launch_admm_wavestream(int nx, int nu, const RowParams &P, hipStream_t stream);
 

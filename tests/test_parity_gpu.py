@@ -1169,3 +1169,30 @@ def test_randomised_differential_tools_short_run(tool):
     root = Path(__file__).resolve().parents[1]
     r = subprocess.run([sys.executable, str(root / "tools" / tool), "6", "1"], capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("dims", [(16, 8, 10), (16, 4, 12)])
+def test_wave_kernel_other_classes(tinympc, oracle_mod, dims):
+    """Two more classes of the wave-per-instance kernel, each pinned against its own reference build in test_oracle.py:
+    (16,8) takes Eigen's GEMV path like (32,16), (16,4) does not."""
+    O, pr = oracle_mod, tinympc.problems
+    nx, nu, N = dims
+    prob = pr.random_system(nx, nu, N, seed=nx * 100 + nu)
+    B = 21
+    rng = np.random.default_rng(nx + nu)
+    x0 = rng.uniform(-0.5, 0.5, size=(B, nx)).astype(np.float32)
+    xref = (rng.standard_normal((B, N, nx)) * 0.2).astype(np.float32)
+    bnds = pr.bounds_arrays(prob)
+    settings = dict(O.DEFAULT_SETTINGS, max_iter=40, check_termination=2)
+    sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+    assert sol.kernel_name() == f"wavestream<{nx},{nu},exact>", sol.kernel_name()
+    sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
+    orc = O.Oracle(prob, np.float32, settings)
+    st = O.new_state(B, nx, nu, N); st["x"][:, 0] = x0
+    for k in range(3):
+        st["y"][:] = 0; st["g"][:] = 0
+        sol.reset_dual_variables()
+        orc.solve(st, *bnds, xref, nthreads=8)
+        sol.solve()
+        assert_bitwise(sol.get_state(), st, f"wave {dims} k={k}")
+    sol.close()

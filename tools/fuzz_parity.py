@@ -20,7 +20,7 @@ pr = T.problems
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 CLASSES = [("quad", 30), ("quad", 25), ("quad", 20), ("quad", 10), ("quad", 17), ("quad", 7), ("quad", 36), ("cartpole", 10),
-           ("cartpole", 23), ("odd", 7), ("odd", 13), ("rand32", 50), ("r8_4", 9), ("r12_2", 14), ("r4_2", 8), ("r4_4", 35)]
+           ("cartpole", 23), ("odd", 7), ("odd", 13), ("rand32", 50), ("r8_4", 9), ("r12_2", 14), ("r4_2", 8), ("r4_4", 35), ("w16_8", 10), ("w16_4", 12)]
 t_end, rounds, solves, t_note, overflowed = time.time() + budget, 0, 0, time.time(), 0
 while time.time() < t_end:
     if time.time() - t_note > 30:
@@ -33,7 +33,8 @@ while time.time() < t_end:
         prob = {"quad": lambda: pr.quadrotor(20, N), "cartpole": lambda: pr.cartpole(N), "odd": lambda: pr.random_system(8, 3, N, seed=99),
                 "rand32": lambda: pr.random_system(32, 16, N)}[kind]()
     nx, nu = prob["nx"], prob["nu"]
-    B = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 200])) if kind != "rand32" else int(rng.choice([1, 3, 9]))
+    wave = kind == "rand32" or kind.startswith("w")
+    B = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 200])) if not wave else int(rng.choice([1, 3, 9]))
     settings = dict(abs_pri_tol=float(rng.choice([0.0, 1e-3, 1e-2, 0.5])), abs_dua_tol=float(rng.choice([0.0, 1e-3, 1e-1, 5.0])),
                     max_iter=int(rng.choice([0, 1, 2, 3, 7, 20, 45])), check_termination=int(rng.choice([1, 1, 2, 3, 7])),
                     en_state_bound=int(rng.integers(2)), en_input_bound=int(rng.integers(2)))
@@ -49,11 +50,11 @@ while time.time() < t_end:
         bnds = tuple((a[None] * rng.uniform(0.3, 1.0, size=(B,) + a.shape)).astype(np.float32) for a in bnds)
     bnds_raw = bnds
     sol = T.TinyBatchSolver(prob, B, settings=settings)
-    h16 = kind != "rand32" and rng.random() < 0.3   # fp16 storage / fp32 arithmetic against the oracle's _h16 restatement
+    h16 = not wave and rng.random() < 0.3   # fp16 storage / fp32 arithmetic against the oracle's _h16 restatement
     if h16:
         sol.set_storage(16)
     R = O.round_h16 if h16 else (lambda a: a)
-    fams = [0] + ([f for f in (1, 2, 3, 4) if kind != "rand32"])
+    fams = [0] + ([f for f in (1, 2, 3, 4) if not wave])
     fam = int(rng.choice(fams))
     try:
         sol.set_row_kernel(fam)
