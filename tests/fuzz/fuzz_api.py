@@ -1,14 +1,14 @@
 """Randomised check of the host-side state machine (run on an MI355X): random sequences of set_x0 / reset_dual_variables /
 reset_workspace (both folded lazily into the next solve) / set_array / set_status / kernel and row-family switches (device
 layout conversion) / solve / get_*, mirrored on a numpy model that is advanced with the CPU oracle.  Every read must equal the
-model bit for bit.      python tools/fuzz_api.py [seconds] [seed]"""
+model bit for bit.      python tests/fuzz/fuzz_api.py [seconds] [seed]"""
 import sys
 import time
 from pathlib import Path
 
 import numpy as np
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import accelerated_tinympc_amd as T  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 

@@ -1,13 +1,13 @@
 """Randomised consistency check (run on an MI355X): in fma arithmetic the three 16-lane row kernels (unrolled, rolled, state
 in HBM) share their step arithmetic (rowlane_math.h), so they must agree with each other bit for bit even though none of them
-is bit-comparable with the reference.      python tools/fuzz_fast_families.py [seconds] [seed]"""
+is bit-comparable with the reference.      python tests/fuzz/fuzz_fast_families.py [seconds] [seed]"""
 import sys
 import time
 from pathlib import Path
 
 import numpy as np
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import accelerated_tinympc_amd as T  # noqa: E402
 
 pr = T.problems

@@ -1,13 +1,13 @@
 """Randomised check (run on an MI355X): tiny_batch_mpc_run_async(K) — on-chip closed loop or graph replay — must leave exactly
 the state of K calls of tiny_batch_mpc_step_async, for random classes, kernels, arithmetic modes, batches, settings,
-window advances and step counts.      python tools/fuzz_mpc.py [seconds] [seed]"""
+window advances and step counts.      python tests/fuzz/fuzz_mpc.py [seconds] [seed]"""
 import sys
 import time
 from pathlib import Path
 
 import numpy as np
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import accelerated_tinympc_amd as T  # noqa: E402
 
 pr = T.problems

@@ -1,14 +1,14 @@
 """Randomised check of the native-names compatibility API (include/tinympc_admm.h; run on an MI355X): random sequences of
 tiny_solve / forward_pass / update_slack / update_dual / update_linear_cost / termination_condition / backward_pass_grad on a
 caller-owned TinySolver whose bounds, reference, settings and gains change between calls, mirrored with the CPU oracle.
-      python tools/fuzz_native.py [seconds] [seed]"""
+      python tests/fuzz/fuzz_native.py [seconds] [seed]"""
 import sys
 import time
 from pathlib import Path
 
 import numpy as np
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import accelerated_tinympc_amd as T  # noqa: E402
 from accelerated_tinympc_amd import native  # noqa: E402
 from oracle import oracle as O  # noqa: E402

@@ -1,6 +1,6 @@
 """Randomised differential test of the exact kernels against the CPU oracle (test infrastructure; run on an MI355X):
 
-    python tools/fuzz_parity.py [seconds] [seed]
+    python tests/fuzz/fuzz_parity.py [seconds] [seed]
 
 Every round draws a problem class with an exact kernel, a batch size, settings (iteration limits, termination stride,
 tolerances, bound switches), bounds (per step, some infeasible or infinite), a reference (shared / per instance / sliding
@@ -12,7 +12,7 @@ from pathlib import Path
 
 import numpy as np
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import accelerated_tinympc_amd as T  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 

@@ -1,8 +1,8 @@
 """Randomised consistency check of the MFMA streaming kernel (run on an MI355X): at a FIXED iteration count (tolerances 0, so no
 early-exit decisions can differ) its x, u, d, p must agree with the row kernels (fma arithmetic for nx + nu <= 16, the exact wave
 kernel for nx = 32) to rounding level, for random classes, ragged batches, settings and warm starts.
-      python tools/fuzz_stream_consistency.py [seconds]"""
-import sys, time; sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))
+      python tests/fuzz/fuzz_stream_consistency.py [seconds]"""
+import sys, time; sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[2]))
 import numpy as np
 import accelerated_tinympc_amd as T
 pr=T.problems

@@ -3,7 +3,7 @@ own fp64 build is from its fp32 build (the algorithm's intrinsic rounding sensit
 import sys
 from pathlib import Path
 import numpy as np
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import accelerated_tinympc_amd as T
 from oracle import oracle as O
 

@@ -12,7 +12,7 @@ FAST arithmetic (fma chains: v_mfma_f32_16x16x4_f32 in the streaming kernel, v_f
   rowlane kernel): one rounding per multiply-add instead of two, so bit equality is impossible.  ADMM
   with the examples' early exit (residual < 1e-3) is rounding sensitive: the reference's OWN fp64 and fp32
   builds disagree on the iteration count of ~47 % of the tracking instances and on u by up to 6e-5
-  (tools/parity_yardstick.py).  BASELINE.json's "u* within 1e-5" therefore cannot be met even by the
+  (tests/fuzz/parity_yardstick.py).  BASELINE.json's "u* within 1e-5" therefore cannot be met even by the
   reference against itself; the bar used instead is the reference's own precision spread, measured on the
   same inputs with the fp64 oracle (bit-exact with the reference's fp64 build, tests/test_oracle.py):
     * per array, over instances whose iteration count agrees, relative inf-norm error (normalised by
@@ -1133,7 +1133,7 @@ def test_per_instance_bounds_exact(tinympc, oracle_mod):
 def test_cold_start_that_converges_immediately(tinympc, oracle_mod, variant_name):
     """reset_workspace() then a solve from x0 = 0 with a zero reference converges in its first iteration, before any backward
     sweep: p, d, v, z must read back as the zeros reset_workspace() promised (not whatever an earlier solve left in memory),
-    and x, u follow from d = 0.  Found by tools/fuzz_api.py on the kernels that stream their state."""
+    and x, u follow from d = 0.  Found by tests/fuzz/fuzz_api.py on the kernels that stream their state."""
     O, pr = oracle_mod, tinympc.problems
     for prob in (pr.quadrotor(20, 30), pr.cartpole(10), pr.random_system(32, 16, 50)):
         nx, nu, N = prob["nx"], prob["nu"], prob["N"]
@@ -1161,13 +1161,13 @@ def test_cold_start_that_converges_immediately(tinympc, oracle_mod, variant_name
 @pytest.mark.parametrize("tool", ["fuzz_parity.py", "fuzz_mpc.py", "fuzz_api.py", "fuzz_native.py", "fuzz_fast_families.py",
                                   "fuzz_stream_consistency.py"])
 def test_randomised_differential_tools_short_run(tool):
-    """A few seconds of each randomised differential tool (tools/fuzz_*.py; the minutes-long runs are recorded in DESIGN.md),
+    """A few seconds of each randomised differential tool (tests/fuzz/fuzz_*.py; the minutes-long runs are recorded in DESIGN.md),
     with a fixed seed so that the test is reproducible: keeps the tools working and replays a few thousand drawn cases."""
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
-    r = subprocess.run([sys.executable, str(root / "tools" / tool), "6", "1"], capture_output=True, text=True, timeout=300, cwd=root)
+    r = subprocess.run([sys.executable, str(root / "tests" / "fuzz" / tool), "6", "1"], capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
