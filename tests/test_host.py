@@ -31,6 +31,26 @@ def test_product_does_not_reference_the_oracle():
         txt = p.read_text()
         assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), p
         assert "libtinympc_oracle" not in txt and "oracle/" not in txt.replace("oracle/ ", ""), p
+    # outside the package, only tests/, __graft_entry__.py (smoke) and bench.py (cpu_baseline) may import the oracle
+    allowed = {ROOT / "bench.py", ROOT / "__graft_entry__.py"}
+    for d in ("tools", "examples", "include"):
+        for p in (ROOT / d).rglob("*"):
+            if p.is_file() and p.suffix in (".py", ".sh", ".cpp", ".h", ".hip"):
+                txt = p.read_text()
+                assert not re.search(r"^\s*(from|import)\s+oracle|from oracle import|libtinympc_oracle", txt, re.M), p
+    for p in ROOT.glob("*.py"):
+        if p not in allowed:
+            assert not re.search(r"^\s*(from|import)\s+oracle|from oracle import", p.read_text(), re.M), p
+    # bench.py touches the oracle only inside its cpu_baseline leg
+    import ast
+    tree = ast.parse((ROOT / "bench.py").read_text())
+    for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.Module))]:
+        body = fn.body if isinstance(fn, ast.Module) else [n for n in ast.walk(fn)]
+        for n in body:
+            if isinstance(n, (ast.Import, ast.ImportFrom)):
+                mods = [a.name for a in n.names] + [getattr(n, "module", "") or ""]
+                if any(m.split(".")[0] == "oracle" for m in mods):
+                    assert isinstance(fn, ast.FunctionDef) and fn.name == "cpu_baseline", (fn, n.lineno)
 
 
 def test_host_riccati_matches_reference_codegen(tinympc):
