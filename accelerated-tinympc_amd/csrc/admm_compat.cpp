@@ -17,11 +17,12 @@ struct Ctx
     TinyBatch *tb = nullptr;
     int nx = 0, nu = 0, N = 0, device = 0;
     // last uploaded problem class / inputs, to skip unchanged uploads
-    std::vector<float> gains, bnd[4], xref;
+    std::vector<float> gains, bnd[4], xref, opt;
     float rho = 0.f;
 };
 Ctx g_ctx;
 int g_device = 0;
+int g_en_uref = 0, g_en_d2p = 0; // tiny_admm_set_optional_terms
 int g_code = 0;
 
 int report(const char *what, int rc)
@@ -95,6 +96,23 @@ int prepare(const TinySolver *s)
         TRYRC(tiny_batch_set_xref(C.tb, w->Xref, 1));
         C.xref.assign(w->Xref, w->Xref + (size_t)nx * N);
     }
+    // the two terms the reference ships commented out (admm.cpp:20, :79): members read only when switched on
+    if (g_en_uref) { NEED(w->R); NEED(w->Uref); }
+    if (g_en_d2p) NEED(c->coeff_d2p);
+    std::vector<float> opt;
+    if (g_en_uref) { opt.insert(opt.end(), w->R, w->R + nu); opt.insert(opt.end(), w->Uref, w->Uref + (size_t)nu * (N - 1)); }
+    if (g_en_d2p) opt.insert(opt.end(), c->coeff_d2p, c->coeff_d2p + (size_t)nx * nu);
+    if (opt != C.opt)
+    {
+        if (g_en_uref)
+        {
+            TRYRC(tiny_batch_set_input_cost(C.tb, w->R));
+            TRYRC(tiny_batch_set_uref(C.tb, w->Uref, 1));
+        }
+        if (g_en_d2p) TRYRC(tiny_batch_set_coeff_d2p(C.tb, c->coeff_d2p));
+        C.opt.swap(opt);
+    }
+    TRYRC(tiny_batch_set_optional_terms(C.tb, g_en_uref, g_en_d2p));
     return 0;
 }
 
@@ -146,6 +164,13 @@ int tiny_admm_set_device(int device)
     return 0;
 }
 int tiny_admm_last_error_code(void) { return g_code; }
+int tiny_admm_set_optional_terms(int en_uref, int en_coeff_d2p)
+{
+    g_en_uref = en_uref != 0;
+    g_en_d2p = en_coeff_d2p != 0;
+    g_ctx.opt.clear();
+    return 0;
+}
 
 int tiny_solve(TinySolver *s) // admm.cpp:111-152
 {

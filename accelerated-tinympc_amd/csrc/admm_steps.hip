@@ -10,6 +10,26 @@
 namespace tinympc
 {
 
+// gain rows of the optional terms (pack_gains): R on the u rows, then coeff_d2p(r, m) on the x rows
+template <int NX, int NU>
+__device__ __forceinline__ float input_cost_row(const float *mats, int r16) { return mats[(3 * NX + 2 * NU + 1) * 16 + r16]; }
+template <int NX, int NU>
+__device__ __forceinline__ void load_d2p(float (&CD)[NU], const float *mats, int r16)
+{
+#pragma unroll
+    for (int m = 0; m < NU; m++) CD[m] = mats[(3 * NX + 2 * NU + 2 + m) * 16 + r16];
+}
+
+// c term of a step (what lin_cost() subtracts rho*(snew - dual) from): x rows -(Xref .* Q) (admm.cpp:81); u rows -0, so that
+// r = -rho*(znew - y) keeps the sign of a zero difference, or -(Uref .* R) when the optional input reference is on
+template <bool H16>
+__device__ __forceinline__ float cost_of(const RowParams &P, bool is_x, bool is_u, float xr, float qrow, float rrow, int uoff)
+{
+    if (is_x) return rnd<H16>(-(xr * qrow));
+    if (P.uref != nullptr && is_u) return rnd<H16>(-(ldw<H16>(P.uref, uoff) * rrow));
+    return -0.f;
+}
+
 template <int NX, int NU, bool EXACT, bool H16>
 __global__ __launch_bounds__(WAVE) void admm_step_kernel(const RowParams P, const int fn, int *__restrict__ conv_out)
 {
@@ -54,10 +74,10 @@ __global__ __launch_bounds__(WAVE) void admm_step_kernel(const RowParams P, cons
     }
     else if (fn == STEP_UPDATE_LINEAR_COST) // admm.cpp:77-85  r, q, p.col(N-1)
     {
-        const float qrow = P.mats[(2 * NX + 2 * NU) * 16 + r16];
+        const float qrow = P.mats[(2 * NX + 2 * NU) * 16 + r16], rrow = input_cost_row<NX, NU>(P.mats, r16);
         int wstart = 0;
         if (P.xref_mode == 1 && valid) wstart = P.xref_start[inst];
-        const int xref_off = inst * (int)P.xref_inst_stride + r16;
+        const int xref_off = inst * (int)P.xref_inst_stride + r16, uref_off = inst * (int)P.uref_inst_stride + r16;
         float xr = 0.f, t1 = 0.f;
         for (int i = 0; i < N; i++)
         {
@@ -69,7 +89,7 @@ __global__ __launch_bounds__(WAVE) void admm_step_kernel(const RowParams P, cons
             }
             else
                 xr = ldw<H16>(P.xref, xref_off + i * 16);
-            const float cq = is_x ? rnd<H16>(-(xr * qrow)) : -0.f; // -0: r = -rho*(znew - y) keeps the sign of a zero difference
+            const float cq = cost_of<H16>(P, is_x, is_u, xr, qrow, rrow, uref_off + i * 16);
             t1 = ldw<H16>(P.vzn, rowbase + i * 16) - ldw<H16>(P.gy, rowbase + i * 16);
             const float lin = lin_cost<EXACT, H16>(cq, rho, t1);
             if (valid) stw<H16>(P.qr, rowbase + i * 16, (i < N - 1 || is_x) ? lin : 0.f);
@@ -109,11 +129,14 @@ __global__ __launch_bounds__(WAVE) void admm_step_kernel(const RowParams P, cons
     {
         RowGains<NX, NU> G;
         G.load(P.mats, r16);
+        float CD[NU];
+        load_d2p<NX, NU>(CD, P.mats, r16);
         float p = ldw<H16>(P.pd, rowbase + (N - 1) * 16);
         for (int i = N - 2; i >= 0; i--)
         {
             float pn, dd;
             riccati_step<NX, NU, EXACT, H16>(G, is_x, p, ldw<H16>(P.qr, rowbase + i * 16), pn, dd);
+            if (P.en_d2p) pn = d2p_term<NX, NU, EXACT, H16>(CD, pn, dd);
             if (valid) stw<H16>(P.pd, rowbase + i * 16, is_u ? dd : pn);
             p = pn;
         }
@@ -140,10 +163,12 @@ __global__ __launch_bounds__(WAVE) void admm_rowstream_kernel(const RowParams P)
     const float rho = P.rho;
     RowGains<NX, NU> G;
     G.load(P.mats, r16);
-    const float qrow = P.mats[(2 * NX + 2 * NU) * 16 + r16];
+    const float qrow = P.mats[(2 * NX + 2 * NU) * 16 + r16], rrow = input_cost_row<NX, NU>(P.mats, r16);
+    float CD[NU];
+    load_d2p<NX, NU>(CD, P.mats, r16);
     int wstart = 0;
     if (P.xref_mode == 1 && valid) wstart = P.xref_start[inst];
-    const int xref_off = inst * (int)P.xref_inst_stride + r16;
+    const int xref_off = inst * (int)P.xref_inst_stride + r16, uref_off = inst * (int)P.uref_inst_stride + r16;
     auto xref_at = [&](int i) {
         if (P.xref_mode == 1)
         {
@@ -215,9 +240,10 @@ __global__ __launch_bounds__(WAVE) void admm_rowstream_kernel(const RowParams P)
                 {
                     const int o = rowbase + i * 16;
                     const float sni = ldw<H16>(P.vzn, o);
-                    const float cq = is_x ? rnd<H16>(-(xref_at(i) * qrow)) : -0.f; // -0: r = -rho*(znew - y) keeps the sign of a zero difference
+                    const float cq = cost_of<H16>(P, is_x, is_u, xref_at(i), qrow, rrow, uref_off + i * 16);
                     float pn, dd;
                     riccati_step<NX, NU, EXACT, H16>(G, is_x, p, lin_cost<EXACT, H16>(cq, rho, sni - ldw<H16>(P.gy, o)), pn, dd);
+                    if (P.en_d2p) pn = d2p_term<NX, NU, EXACT, H16>(CD, pn, dd);
                     stw<H16>(P.pd, o, is_u ? dd : pn);
                     stw<H16>(P.vz, o, sni);
                     p = pn;
@@ -247,7 +273,7 @@ __global__ __launch_bounds__(WAVE) void admm_rowstream_kernel(const RowParams P)
             else sv = is_x ? s : 0.f;
             if (valid && solved) stw<H16>(P.xu, o, sv);
             s = xn;
-            const float cq = is_x ? rnd<H16>(-(xref_at(i) * qrow)) : -0.f; // -0: r = -rho*(znew - y) keeps the sign of a zero difference
+            const float cq = cost_of<H16>(P, is_x, is_u, xref_at(i), qrow, rrow, uref_off + i * 16);
             const float lin = lin_cost<EXACT, H16>(cq, rho, ldw<H16>(P.vzn, o) - ldw<H16>(P.gy, o));
             if (valid) stw<H16>(P.qr, o, (i < N - 1 || is_x) ? lin : 0.f);
         }

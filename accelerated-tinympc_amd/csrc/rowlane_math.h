@@ -260,6 +260,26 @@ __device__ __forceinline__ void riccati_step(const RowGains<NX, NU> &G, bool is_
     }
 }
 
+// The term the reference comments out at the end of admm.cpp:20, "+ coeff_d2p * d.col(i)": Eigen assigns the rest of the
+// expression to p.col(i) first (one store, hence the rounding of pn by the caller) and then adds the product, which it
+// evaluates into a temporary in sequential order (measured; the test suite pins it against Eigen).  CD[m] = coeff_d2p(r, m) on x rows.
+template <int NX, int NU, bool EXACT, bool H16 = false>
+__device__ __forceinline__ float d2p_term(const float (&CD)[NU], float pn, float dd)
+{
+    if constexpr (EXACT)
+    {
+        float t[NU];
+        dpp_products<NX, NU>(t, dd, CD);
+        return rnd<H16>(pn + reduce<PLAN_SEQ>(t));
+    }
+    else
+    {
+        float acc = pn;
+        dpp_fma_acc<NX, NU>(acc, dd, CD);
+        return rnd<H16>(acc);
+    }
+}
+
 // cost term of a step as lin_cost() wants it: x rows keep c = -(Xref.*Q), u rows (where c holds d) get NEGATIVE zero, so that
 // cq - rho*t1 equals the reference's r = -rho*(znew - y) also in the sign of a zero (one v_and_or_b32)
 __device__ __forceinline__ float cost_term(float c, bool is_x)

@@ -248,6 +248,11 @@ struct TinyBatch
     size_t xfam_floats = 0, ufam_floats = 0, pair_floats = 0;
     // caller inputs (canonical) and their per-layout derived forms
     InputArr in_xref, in_bnd[4]; // bnd: xmin, xmax, umin, umax
+    // the two terms the reference ships commented out (admm.cpp:20, :79); tiny_batch_set_optional_terms
+    bool en_uref = false, en_d2p = false, have_rcost = false;
+    std::vector<float> Rcost, coeff_d2p; // R [nu], coeff_d2p [nx x nu] column-major
+    InputArr in_uref;                    // [batch or 1][N-1][nu]
+    float *r_uref = nullptr;             // ROW derived: [batch_pad4 or 1][N][rw], Uref on the u rows
     bool derived_dirty[2] = {true, true};
     float *t_xref = nullptr, *t_bnd[4] = {};              // TILE derived
     float *r_xref = nullptr, *r_bounds = nullptr;         // ROW derived
@@ -539,7 +544,7 @@ int pack_gains(TinyBatch *tb)
         for (int fast = 0; fast < 2; fast++)
         {
             const float sg = fast ? -1.f : 1.f;
-            const int nreg = 3 * nx + 2 * nu + 1;
+            const int nreg = 3 * nx + 3 * nu + 2; // ... + R (u rows) + coeff_d2p(r, m) (x rows): the optional terms
             std::vector<float> m((size_t)nreg * RW, 0.f);
             for (int r = 0; r < RW; r++)
             {
@@ -557,6 +562,9 @@ int pack_gains(TinyBatch *tb)
                     m[(size_t)(2 * nx + nu + mm) * RW + r] = isx ? sg * Kat(mm, r) : (isu ? Qiat(mr, mm) : 0.f);
                 }
                 m[(size_t)(2 * nx + 2 * nu) * RW + r] = isx ? tb->Q[r] : 0.f;
+                m[(size_t)(3 * nx + 2 * nu + 1) * RW + r] = (isu && tb->have_rcost) ? tb->Rcost[mr] : 0.f;
+                for (int mm = 0; mm < nu; mm++)
+                    m[(size_t)(3 * nx + 2 * nu + 2 + mm) * RW + r] = (isx && !tb->coeff_d2p.empty()) ? tb->coeff_d2p[(size_t)mm * nx + r] : 0.f;
             }
             TRY(upload_vec(tb, fast ? &tb->mats_fast : &tb->mats_exact, m));
         }
@@ -649,6 +657,13 @@ int prepare_inputs(TinyBatch *tb, int layout)
         TRY(dev_alloc_zero(&tb->r_xref, tb->h16 ? (nf + 1) / 2 : nf));
         if (tb->in_xref.set)
             TRY(launch_pack(tb, tb->in_xref.dev, tb->r_xref, LAYOUT_ROW, 0, tb->in_xref.shared ? 1 : tb->batch, tb->in_xref.shared, 0, N));
+        if (tb->r_uref) { (void)hipFree(tb->r_uref); tb->r_uref = nullptr; }
+        if (tb->in_uref.set) // Uref on the u rows of an [inst][N][rw] array of its own (row N-1 and the x rows stay zero)
+        {
+            const size_t nu_f = (size_t)(tb->in_uref.shared ? 1 : tb->bpad4) * N * RW;
+            TRY(dev_alloc_zero(&tb->r_uref, tb->h16 ? (nu_f + 1) / 2 : nu_f));
+            TRY(launch_pack(tb, tb->in_uref.dev, tb->r_uref, LAYOUT_ROW, 1, tb->in_uref.shared ? 1 : tb->batch, tb->in_uref.shared, 0, N - 1));
+        }
     }
     HIP_TRY(hipStreamSynchronize(tb->stream));
     tb->derived_dirty[layout] = false;
@@ -665,6 +680,9 @@ int resolve_variant(TinyBatch *tb, int *out)
     if (tb->variant == VAR_ROW_FAST && tb->wave_ok)
         return fail(TINY_BATCH_EUNSUPPORTED, "the wave-per-instance kernel (16 < nx + nu <= 64) has exact arithmetic only; fma arithmetic for these sizes is the streaming MFMA kernel (variant 1)");
     if (v == VAR_AUTO) v = row_ok ? VAR_ROW_EXACT : VAR_STREAM;
+    if ((tb->en_uref || tb->en_d2p) && (!tb->rowmath_ok || v == VAR_STREAM))
+        return fail(TINY_BATCH_EUNSUPPORTED, "the optional Uref / coeff_d2p terms (tiny_batch_set_optional_terms) are implemented by the row "
+                                             "kernels for nx + nu <= 16 only (nx=%d nu=%d, variant %d)", tb->nx, tb->nu, v);
     if ((v == VAR_ROW_EXACT || v == VAR_ROW_FAST) && !row_ok)
     {
         return fail(TINY_BATCH_EUNSUPPORTED, "no row kernel instantiation for nx=%d nu=%d (needs nx + nu <= 16)", tb->nx, tb->nu);
@@ -684,6 +702,7 @@ int row_family(const TinyBatch *tb)
 {
     if (tb->wave_ok) return 3; // one wavefront per instance, state in HBM (admm_wave.hip)
     if (!bounds_all_shared(tb)) return 2; // per-instance bounds: only the streaming row kernel reads them per instance
+    if (tb->en_uref || tb->en_d2p) return 2; // the optional terms live in the streaming row kernel (c's u rows hold d elsewhere)
     if (tb->row_family_forced >= 0) return tb->row_family_forced;
     if (tb->quad_ok) return 4; // four lanes per instance (admm_quadlane.hip): nx = 4, nu = 1
     if (tb->row_dims_ok) return 0;
@@ -722,8 +741,20 @@ void fill_row_params(TinyBatch *tb, RowParams &P, bool exact)
     P.bounds = tb->r_bounds;
     P.bounds_inst_stride = bounds_all_shared(tb) ? 0u : (unsigned)(tb->N * tb->rw);
     P.mats = exact ? tb->mats_exact : tb->mats_fast;
+    P.uref = tb->en_uref ? tb->r_uref : nullptr;
+    P.uref_inst_stride = (tb->in_uref.set && !tb->in_uref.shared) ? (unsigned)(tb->N * tb->rw) : 0u;
+    P.en_d2p = tb->en_d2p ? 1 : 0;
     P.res = tb->res; P.status = tb->status; P.iter = tb->iter; P.n_unsolved = tb->n_unsolved;
     P.mpc_steps = 1; P.window_advance = 0; P.u0_traj = nullptr; P.x0buf = tb->x0buf;
+}
+
+int check_optional_terms(const TinyBatch *tb)
+{
+    if (tb->en_uref && (!tb->have_rcost || !tb->in_uref.set))
+        return fail(TINY_BATCH_ENOTREADY, "the Uref term is enabled: tiny_batch_set_input_cost and tiny_batch_set_uref must be called first");
+    if (tb->en_d2p && tb->coeff_d2p.empty())
+        return fail(TINY_BATCH_ENOTREADY, "the coeff_d2p term is enabled: tiny_batch_set_coeff_d2p must be called first");
+    return 0;
 }
 
 // One of the six step functions of admm.hpp:10-18 over the whole batch (admm_steps.hip).
@@ -733,6 +764,7 @@ int run_step(TinyBatch *tb, int fn, int *converged_host, int *n_true)
         return fail(TINY_BATCH_ENOTREADY, "set_cache, set_dynamics and set_settings must be called first");
     if (!tb->rowmath_ok)
         return fail(TINY_BATCH_EUNSUPPORTED, "the single-function kernels need nx + nu <= 16 and an entry in TINY_FOR_EACH_ROWDIMS (nx=%d nu=%d)", tb->nx, tb->nu);
+    TRY(check_optional_terms(tb));
     TRY(set_device(tb));
     if (tb->gains_dirty) TRY(pack_gains(tb));
     TRY(ensure_layout(tb, LAYOUT_ROW));
@@ -768,6 +800,7 @@ int prepare_solve(TinyBatch *tb, int *variant)
         if (lo_inst != hi_inst && (lo.set || hi.set))
             return fail(TINY_BATCH_EINVAL, "min and max bounds must both be shared or both be per-instance");
     }
+    TRY(check_optional_terms(tb));
     TRY(set_device(tb));
     int v = 0;
     TRY(resolve_variant(tb, &v));
@@ -935,6 +968,7 @@ void tiny_batch_destroy(TinyBatch *tb)
     free_layout(tb, LAYOUT_TILE);
     free_layout(tb, LAYOUT_ROW);
     (void)hipFree(tb->in_xref.dev);
+    (void)hipFree(tb->in_uref.dev); (void)hipFree(tb->r_uref);
     for (int k = 0; k < 4; k++) { (void)hipFree(tb->in_bnd[k].dev); (void)hipFree(tb->t_bnd[k]); }
     (void)hipFree(tb->t_xref); (void)hipFree(tb->r_xref); (void)hipFree(tb->r_bounds);
     (void)hipFree(tb->tab_tile); (void)hipFree(tb->tab_row); (void)hipFree(tb->tab_row_h); (void)hipFree(tb->xref_start);
@@ -987,6 +1021,42 @@ int tiny_batch_set_dynamics(TinyBatch *tb, const float *Adyn, const float *Bdyn,
     tb->Q.assign(Q, Q + nx);
     tb->have_dyn = true;
     tb->gains_dirty = true;
+    return 0;
+}
+
+// ---- the two terms the reference ships commented out (admm.cpp:20 and :79), off by default ------------------------------
+int tiny_batch_set_optional_terms(TinyBatch *tb, int en_uref, int en_coeff_d2p)
+{
+    CHECK_TB(tb);
+    tb->en_uref = en_uref != 0;
+    tb->en_d2p = en_coeff_d2p != 0;
+    if (tb->graph_exec) { (void)hipGraphExecDestroy(tb->graph_exec); tb->graph_exec = nullptr; tb->graph_sig.clear(); }
+    update_kname(tb);
+    return 0;
+}
+
+int tiny_batch_set_input_cost(TinyBatch *tb, const float *R)
+{
+    CHECK_TB(tb); CHECK_PTR(R);
+    tb->Rcost.assign(R, R + tb->nu);
+    tb->have_rcost = true;
+    tb->gains_dirty = true;
+    return 0;
+}
+
+int tiny_batch_set_coeff_d2p(TinyBatch *tb, const float *coeff_d2p)
+{
+    CHECK_TB(tb); CHECK_PTR(coeff_d2p);
+    tb->coeff_d2p.assign(coeff_d2p, coeff_d2p + (size_t)tb->nx * tb->nu);
+    tb->gains_dirty = true;
+    return 0;
+}
+
+int tiny_batch_set_uref(TinyBatch *tb, const float *uref, int shared)
+{
+    CHECK_TB(tb); CHECK_PTR(uref);
+    TRY(set_device(tb));
+    TRY(store_input(tb, tb->in_uref, uref, shared != 0, tb->N - 1, tb->nu));
     return 0;
 }
 
@@ -1315,10 +1385,11 @@ int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, 
         tb->stream = tb->own_stream;
     }
     // the graph bakes in kernel arguments: rebuild it whenever anything they depend on may have changed
-    char sig[288];
-    snprintf(sig, sizeof sig, "%d|%d|%d|%s|%d|%d|%g|%g|%d|%d|%p|%p|%p|%d|%p|%p", steps, window_advance, v, tb->kname.c_str(), tb->max_iter,
+    char sig[352];
+    snprintf(sig, sizeof sig, "%d|%d|%d|%s|%d|%d|%g|%g|%d|%d|%p|%p|%p|%d|%p|%p|%p|%p|%d%d", steps, window_advance, v, tb->kname.c_str(), tb->max_iter,
              tb->check_termination, (double)tb->abs_pri_tol, (double)tb->abs_dua_tol, tb->xref_mode, tb->table_rows, (void *)tb->pair[0],
-             (void *)tb->arr[0], (void *)tb->r_bounds, (int)tb->h16, (void *)tb->stream, (void *)d_u0_traj);
+             (void *)tb->arr[0], (void *)tb->r_bounds, (int)tb->h16, (void *)tb->stream, (void *)d_u0_traj, (void *)tb->r_xref,
+             (void *)tb->r_uref, (int)tb->en_uref, (int)tb->en_d2p);
     if (!tb->graph_exec || tb->graph_sig != sig)
     {
         if (tb->graph_exec) { (void)hipGraphExecDestroy(tb->graph_exec); tb->graph_exec = nullptr; }

@@ -94,7 +94,12 @@ struct RowParams
     const float *bounds;         // [N][rw][2] = {lo, hi}; +-inf where a bound is disabled or the row is unused
     unsigned bounds_inst_stride; // {lo,hi} entries between instances: 0 = one table for the batch, N*rw = per-instance bounds
                                  // (streaming row kernel, step kernels and wave kernel only)
-    const float *mats;           // [3nx + 2nu + 1][16] gain rows per lane (see pack_row_mats)
+    const float *mats;           // [3nx + 3nu + 2][16] gain rows per lane (see pack_gains)
+    // the two terms the reference ships commented out (admm.cpp:20, :79), off by default; read by the streaming row kernel
+    // and the step kernels only (tiny_batch_set_optional_terms routes a handle that enables one of them there)
+    const float *uref;           // NULL = off; [batch or 1][N][16], Uref on the u rows (row N-1 zero)
+    unsigned uref_inst_stride;   // floats between instances (0 = shared)
+    int en_d2p;                  // p_i += coeff_d2p * d_i
     float *res;
     int *status, *iter, *n_unsolved;
     // closed loop on chip (admm_rowlane.hip): mpc_steps > 1 runs that many MPC steps (solve; x0 <- Adyn x0 + Bdyn u0;

@@ -60,6 +60,7 @@ def load_wrapper_library(build_if_missing: bool = False) -> C.CDLL:
             getattr(lib, fn).argtypes, getattr(lib, fn).restype = [S], None
         lib.termination_condition.argtypes, lib.termination_condition.restype = [S], C.c_bool
         lib.tiny_admm_set_device.argtypes = [C.c_int]
+        lib.tiny_admm_set_optional_terms.argtypes = [C.c_int, C.c_int]
         _lib = lib
     return _lib
 
@@ -87,6 +88,16 @@ class NativeSolver:
             setattr(self.work, k, p(arr))
         self.work.Q, self.work.Adyn, self.work.Bdyn = p(self.m["Q"]), p(self.m["Adyn"]), p(self.m["Bdyn"])
         self.solver = TinySolver(C.pointer(self.settings), C.pointer(self.cache), C.pointer(self.work))
+        # members the reference never reads unless the optional terms are switched on (admm.cpp:20, :79)
+        self.m["R"] = np.ascontiguousarray(np.asarray(prob.get("R", np.zeros(nu)), np.float32).ravel())
+        self.m["coeff_d2p"] = cm(prob.get("coeff_d2p", np.zeros((nx, nu))))
+        self.a["Uref"] = np.zeros((N - 1, nu), np.float32)
+        self.work.R, self.work.Uref, self.cache.coeff_d2p = p(self.m["R"]), p(self.a["Uref"]), p(self.m["coeff_d2p"])
+        self.lib.tiny_admm_set_optional_terms(0, 0)
+
+    def set_optional_terms(self, en_uref=False, en_coeff_d2p=False):
+        """Process-wide switch of the wrapper library (tiny_admm_set_optional_terms)."""
+        self.lib.tiny_admm_set_optional_terms(int(bool(en_uref)), int(bool(en_coeff_d2p)))
 
     def _check(self):
         code = self.lib.tiny_admm_last_error_code()

@@ -69,6 +69,8 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch_enable_timing": [P, C.c_int], "tiny_batch_last_solve_ms": [P, F],
         "tiny_batch_select_kernel": [P, C.c_int], "tiny_batch_set_storage": [P, C.c_int],
         "tiny_batch_set_row_kernel": [P, C.c_int],
+        "tiny_batch_set_optional_terms": [P, C.c_int, C.c_int], "tiny_batch_set_input_cost": [P, F],
+        "tiny_batch_set_coeff_d2p": [P, F], "tiny_batch_set_uref": [P, F, C.c_int],
         "tiny_batch_group_solve": [C.POINTER(P), C.c_int, I],
         "tiny_batch_set_array_device": [P, C.c_int, P], "tiny_batch_get_array_device": [P, C.c_int, P],
         "tiny_batch_set_xref_device": [P, P, C.c_int],
@@ -194,6 +196,22 @@ class TinyBatchSolver:
 
     def set_xref(self, xref):
         self._set_steps(self.lib.tiny_batch_set_xref, xref, self.N, self.nx)
+
+    # -- the two terms the reference ships commented out (admm.cpp:20, :79); off by default ------------------
+    def set_optional_terms(self, en_uref=False, en_coeff_d2p=False):
+        self._check(self.lib.tiny_batch_set_optional_terms(self._h, int(bool(en_uref)), int(bool(en_coeff_d2p))))
+
+    def set_input_cost(self, R):
+        a = _f32(np.asarray(R).ravel()); assert a.shape == (self.nu,), a.shape
+        self._check(self.lib.tiny_batch_set_input_cost(self._h, _fp(a)))
+
+    def set_coeff_d2p(self, coeff_d2p):
+        assert np.asarray(coeff_d2p).shape == (self.nx, self.nu)
+        a = _colmajor(coeff_d2p)
+        self._check(self.lib.tiny_batch_set_coeff_d2p(self._h, _fp(a)))
+
+    def set_uref(self, uref):
+        self._set_steps(self.lib.tiny_batch_set_uref, uref, self.N - 1, self.nu)
 
     def set_xref_window(self, table, start):
         t = _f32(table); s = np.ascontiguousarray(start, dtype=np.int32)

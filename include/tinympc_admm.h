@@ -28,7 +28,8 @@ extern "C"
     typedef float tinytype; /* codegen.cpp:152: generated code is always float */
 
     /* types.hpp:26-34.  Matrices column-major: Kinf nu x nx, Pinf nx x nx, Quu_inv nu x nu, AmBKt nx x nx.
-     * coeff_d2p (nx x nu) is never read by the solver (admm.cpp:20 has the term commented out); may be NULL. */
+     * coeff_d2p (nx x nu) is not read by the solver (admm.cpp:20 has the term commented out) and may be NULL, unless
+     * tiny_admm_set_optional_terms() switches the term on. */
     typedef struct
     {
         tinytype rho;
@@ -51,7 +52,8 @@ extern "C"
     } TinySettings;
 
     /* types.hpp:52-97, same member names and order.  State-type members are nx x N, input-type members nu x (N-1),
-     * column-major (element (i,j) at j*rows + i), caller-allocated.  R, Uref, Qu are never read (admm.cpp:79); may be NULL. */
+     * column-major (element (i,j) at j*rows + i), caller-allocated.  R, Uref, Qu are not read (admm.cpp:79) and may be NULL;
+     * tiny_admm_set_optional_terms() makes R and Uref live. */
     typedef struct
     {
         int nx, nu, N; /* NSTATES, NINPUTS, NHORIZON of glob_opts.hpp */
@@ -117,6 +119,10 @@ extern "C"
      * message via tiny_batch_last_error()). */
     int tiny_admm_set_device(int device);
     int tiny_admm_last_error_code(void);
+    /* Switch on the two terms the reference ships commented out, for every later call: en_coeff_d2p adds
+     * "+ coeff_d2p * d.col(i)" in backward_pass_grad (admm.cpp:20), en_uref makes update_linear_cost compute
+     * r = -(Uref o R) - rho*(znew - y) (what admm.cpp:79 stands for).  Both off by default = the reference as shipped. */
+    int tiny_admm_set_optional_terms(int en_uref, int en_coeff_d2p);
 
 #ifdef __cplusplus
 }

@@ -186,6 +186,22 @@ extern "C"
      * are rounded when they are stored.  Changing the precision restarts the workspace from zero, like create. */
     int tiny_batch_set_storage(TinyBatch *tb, int bits);
 
+    /* ---- the two terms the reference ships commented out, off by default ----
+     * en_coeff_d2p: backward_pass_grad adds "+ coeff_d2p * d.col(i)" to p.col(i) (the trailing comment of
+     * src/tinympc/admm.cpp:20; TinyCache::coeff_d2p, types.hpp:33).  en_uref: update_linear_cost computes
+     * r = -(Uref o R) - rho*(znew - y) with TinyWorkspace::Uref and ::R (types.hpp:93,83) — the input-side twin of
+     * admm.cpp:81-82, which is what the line commented out at admm.cpp:79 stands for.  A handle with a term switched on
+     * runs the row kernel that streams its state (and the step kernels); nx + nu <= 16, variants 0/2/3.  With both off
+     * (the default) nothing changes anywhere.  In exact arithmetic the results are bit-identical to Eigen evaluating
+     * those expressions over the reference's types (pinned by the test suite). */
+    int tiny_batch_set_optional_terms(TinyBatch *tb, int en_uref, int en_coeff_d2p);
+    /* R: nu input-cost weights as stored in TinyWorkspace::R (types.hpp:83; the reference's codegen stores R + rho there) */
+    int tiny_batch_set_input_cost(TinyBatch *tb, const float *R);
+    /* coeff_d2p: nx x nu, column-major (types.hpp:33; tiny_riccati() computes it) */
+    int tiny_batch_set_coeff_d2p(TinyBatch *tb, const float *coeff_d2p);
+    /* Uref: [N-1][nu] when shared != 0, else [batch][N-1][nu] (types.hpp:93) */
+    int tiny_batch_set_uref(TinyBatch *tb, const float *uref, int shared);
+
     /* ---- offline setup: Riccati cache precompute (src/tinympc/codegen.cpp:254-292), fp64, host ---- */
     /* A (nx x nx), B (nx x nu) column-major; Q (nx), R (nu) diagonals WITHOUT rho (the routine adds it,
      * codegen.cpp:255-256).  Outputs column-major.  *iters = Riccati iterations run (1000 = not converged,

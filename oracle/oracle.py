@@ -74,7 +74,8 @@ def _problem_struct(T):
                     ("AmBKt", C.POINTER(T.ct)), ("Adyn", C.POINTER(T.ct)), ("Bdyn", C.POINTER(T.ct)),
                     ("Q", C.POINTER(T.ct)), ("abs_pri_tol", T.ct), ("abs_dua_tol", T.ct),
                     ("max_iter", C.c_int), ("check_termination", C.c_int),
-                    ("en_state_bound", C.c_int), ("en_input_bound", C.c_int)]
+                    ("en_state_bound", C.c_int), ("en_input_bound", C.c_int),
+                    ("en_uref", C.c_int), ("en_coeff_d2p", C.c_int), ("R", C.POINTER(T.ct)), ("coeff_d2p", C.POINTER(T.ct))]
     return OracleProblem
 
 
@@ -84,7 +85,8 @@ def _work_struct(T):
     class OracleWork(C.Structure):
         _fields_ = ([(n, P) for n in STATE_ORDER] + [(n, P) for n in ("u_min", "u_max", "x_min", "x_max", "Xref")] +
                     [("primal_residual_state", T.ct), ("primal_residual_input", T.ct),
-                     ("dual_residual_state", T.ct), ("dual_residual_input", T.ct), ("status", C.c_int), ("iter", C.c_int)])
+                     ("dual_residual_state", T.ct), ("dual_residual_input", T.ct), ("status", C.c_int), ("iter", C.c_int),
+                     ("Uref", P)])
     return OracleWork
 
 
@@ -96,12 +98,15 @@ def _batch_struct(T):
                     [(n, P) for n in ("u_min", "u_max", "x_min", "x_max", "Xref")] +
                     [("bound_stride_x", C.c_longlong), ("bound_stride_u", C.c_longlong),
                      ("xref_stride", C.c_longlong), ("residuals", P),
-                     ("status", C.POINTER(C.c_int)), ("iter", C.POINTER(C.c_int))])
+                     ("status", C.POINTER(C.c_int)), ("iter", C.POINTER(C.c_int)),
+                     ("Uref", P), ("uref_stride", C.c_longlong)])
     return OracleBatch
 
 
 DEFAULT_SETTINGS = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1,
                         en_state_bound=1, en_input_bound=1)  # examples/quadrotor_hovering.cpp:73-78
+# Optional terms (commented out in the reference, admm.cpp:20 and :79; off unless asked for): settings["en_uref"] with
+# prob["R"] and set_uref(), settings["en_coeff_d2p"] with prob["coeff_d2p"].
 
 
 def new_state(B, nx, nu, N, dtype=np.float32):
@@ -141,7 +146,21 @@ class _Solver:
         dt = self.T.np
         self._m = {k: _colmajor(prob[k], dt) for k in ("Kinf", "Pinf", "Quu_inv", "AmBKt", "Adyn", "Bdyn")}
         self._m["Q"] = np.ascontiguousarray(np.asarray(prob["Q"], dt).ravel())
+        self._m["R"] = np.ascontiguousarray(np.asarray(prob.get("R", np.zeros(self.nu)), dt).ravel())
+        self._m["coeff_d2p"] = _colmajor(prob.get("coeff_d2p", np.zeros((self.nx, self.nu))), dt)
+        assert self._m["R"].size == self.nu and self._m["coeff_d2p"].size == self.nx * self.nu
         self.rho = dt.type(prob["rho"])
+        self._uref = None
+
+    def set_uref(self, Uref):
+        """Input reference of the optional Uref term: (N-1, nu) shared or (B, N-1, nu); used only when settings["en_uref"]."""
+        self._uref = None if Uref is None else np.ascontiguousarray(np.asarray(Uref, self.T.np))
+
+    def _uref_arg(self, B):
+        if not self.settings.get("en_uref"):
+            return None, 0
+        assert self._uref is not None, "en_uref needs set_uref()"
+        return _bcast(self._uref, B, (self.N - 1, self.nu), self.T.np)
 
     def _prep(self, st, x_min, x_max, u_min, u_max, Xref):
         dt = self.T.np
@@ -185,7 +204,8 @@ class Oracle(_Solver):
         return self.PS(self.nx, self.nu, self.N, self.rho, *[_ptr(self._m[k], ct) for k in
                        ("Kinf", "Pinf", "Quu_inv", "AmBKt", "Adyn", "Bdyn", "Q")],
                        s["abs_pri_tol"], s["abs_dua_tol"], s["max_iter"], s["check_termination"],
-                       s["en_state_bound"], s["en_input_bound"])
+                       s["en_state_bound"], s["en_input_bound"], int(bool(s.get("en_uref"))), int(bool(s.get("en_coeff_d2p"))),
+                       _ptr(self._m["R"], ct), _ptr(self._m["coeff_d2p"], ct))
 
     STEP_FUNCTIONS = ("forward_pass", "update_slack", "update_dual", "update_linear_cost", "termination_condition",
                       "backward_pass_grad")
@@ -201,6 +221,7 @@ class Oracle(_Solver):
         ps = self._pstruct()
         nxt, nut = self.nx * self.N, self.nu * (self.N - 1)
         out = np.zeros(B, bool)
+        ur, sur = self._uref_arg(B)
         for b in range(B):
             def sl(a, stride, n):
                 flat = a.reshape(-1)
@@ -208,7 +229,8 @@ class Oracle(_Solver):
             ptrs = [sl(st[k], nxt if k in STATE_X else nut, nxt if k in STATE_X else nut) for k in STATE_ORDER]
             inp = [sl(ins[0], su, nut), sl(ins[1], su, nut), sl(ins[2], sx, nxt), sl(ins[3], sx, nxt), sl(ins[4], sr, nxt)]
             r = st["residuals"][b]
-            w = WS(*ptrs, *inp, r[0], r[1], r[2], r[3], int(st["status"][b]), int(st["iter"][b]))
+            w = WS(*ptrs, *inp, r[0], r[1], r[2], r[3], int(st["status"][b]), int(st["iter"][b]),
+                   sl(ur, sur, nut) if ur is not None else None)
             rv = f(C.byref(ps), C.byref(w))
             if fn == "termination_condition":
                 out[b] = bool(rv)
@@ -221,8 +243,10 @@ class Oracle(_Solver):
         B, ins, (sx, su, sr) = self._prep(st, x_min, x_max, u_min, u_max, Xref)
         ct = self.T.ct
         self.lib.oracle_set_ftz_daz(1 if ftz else 0)
+        ur, sur = self._uref_arg(B)
         bs = self.BS(B, *[_ptr(st[k], ct) for k in STATE_ORDER], *[_ptr(a, ct) for a in ins],
-                     sx, su, sr, _ptr(st["residuals"], ct), _ptr(st["status"], C.c_int), _ptr(st["iter"], C.c_int))
+                     sx, su, sr, _ptr(st["residuals"], ct), _ptr(st["status"], C.c_int), _ptr(st["iter"], C.c_int),
+                     _ptr(ur, ct) if ur is not None else None, sur)
         ps = self._pstruct()
         rc = self.fn(C.byref(ps), C.byref(bs), int(nthreads))
         self.lib.oracle_set_ftz_daz(0)
@@ -263,6 +287,7 @@ class Reference(_Solver):
 
     def solve(self, st, x_min, x_max, u_min, u_max, Xref, nthreads=1, ftz=False):
         assert nthreads == 1, "the reference is single-threaded (one global solver, tiny_wrapper.cpp)"
+        assert not self.settings.get("en_uref") and not self.settings.get("en_coeff_d2p"), "commented out in the reference"
         B, ins, (sx, su, sr) = self._prep(st, x_min, x_max, u_min, u_max, Xref)
         ct = self.T.ct
         s = self.settings

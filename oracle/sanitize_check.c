@@ -27,7 +27,12 @@ static double urand(unsigned *s) { *s = *s * 1664525u + 1013904223u; return (dou
         for (int i = 0; i < NU * NU; i++) Qi[i] = (REAL)(0.1 * urand(&seed));                                        \
         for (int i = 0; i < NX * NU; i++) B[i] = (REAL)(0.3 * urand(&seed));                                         \
         for (int i = 0; i < NX; i++) Q[i] = (REAL)(1.0 + i);                                                         \
-        OracleProblem##SUF pr = {NX, NU, NH, (REAL)1.0, K, P, Qi, Am, A, B, Q, (REAL)1e-3, (REAL)1e-3, 25, 2, 1, 1}; \
+        REAL Rr[NU], *Cd = malloc(sizeof(REAL) * NX * NU), *uref = malloc(sizeof(REAL) * (NH - 1) * NU);             \
+        for (int i = 0; i < NU; i++) Rr[i] = (REAL)(0.5 + i);                                                        \
+        for (int i = 0; i < NX * NU; i++) Cd[i] = (REAL)(0.01 * urand(&seed));                                       \
+        for (int i = 0; i < (NH - 1) * NU; i++) uref[i] = (REAL)(0.05 * urand(&seed));                               \
+        /* the two optional terms (admm.cpp:20,79) are switched on so that their loops run under the sanitizers too */ \
+        OracleProblem##SUF pr = {NX, NU, NH, (REAL)1.0, K, P, Qi, Am, A, B, Q, (REAL)1e-3, (REAL)1e-3, 25, 2, 1, 1, 1, 1, Rr, Cd}; \
         const size_t sx = (size_t)NB * NH * NX, su = (size_t)NB * (NH - 1) * NU;                                     \
         REAL *xs[6], *us[6];                                                                                         \
         for (int k = 0; k < 6; k++) { xs[k] = calloc(sx, sizeof(REAL)); us[k] = calloc(su, sizeof(REAL)); }          \
@@ -40,7 +45,7 @@ static double urand(unsigned *s) { *s = *s * 1664525u + 1013904223u; return (dou
         REAL *res = calloc((size_t)NB * 4, sizeof(REAL));                                                            \
         int *status = calloc(NB, sizeof(int)), *iter = calloc(NB, sizeof(int));                                      \
         OracleBatch##SUF bt = {NB, xs[0], us[0], xs[1], us[1], xs[2], us[2], xs[3], xs[4], us[3], us[4], xs[5], us[5],  \
-                              umin, umax, xmin, xmax, xref, 0, 0, (long long)NH * NX, res, status, iter};            \
+                              umin, umax, xmin, xmax, xref, 0, 0, (long long)NH * NX, res, status, iter, uref, 0};   \
         int unsolved = 0;                                                                                            \
         for (int rep = 0; rep < 3; rep++) unsolved = oracle_solve_batch##SUF(&pr, &bt, 2);                           \
         int total = 0;                                                                                               \
@@ -48,7 +53,7 @@ static double urand(unsigned *s) { *s = *s * 1664525u + 1013904223u; return (dou
         printf("%-5s unsolved %d, iterations %d\n", #SUF, unsolved, total);                                          \
         for (int k = 0; k < 6; k++) { free(xs[k]); free(us[k]); }                                                    \
         free(K); free(P); free(Qi); free(Am); free(A); free(B); free(Q); free(umin); free(umax); free(xmin); free(xmax); \
-        free(xref); free(res); free(status); free(iter);                                                             \
+        free(xref); free(res); free(status); free(iter); free(Cd); free(uref);                                       \
         return total > 0 ? 0 : 1;                                                                                    \
     }
 RUN(float, _f32)

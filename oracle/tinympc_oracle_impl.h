@@ -42,6 +42,14 @@ typedef struct SUF(OracleProblem)
     /* TinySettings (types.hpp:39-47) */
     REAL abs_pri_tol, abs_dua_tol;
     int max_iter, check_termination, en_state_bound, en_input_bound;
+    /* The two terms the reference ships commented out (admm.cpp:20 "+ coeff_d2p * d.col(i)", admm.cpp:79 Uref), off by
+     * default.  en_uref: r = -(Uref o R) - rho*(znew - y), the input-side twin of admm.cpp:81-82 (this is what upstream
+     * TinyMPC computes; the line commented out at admm.cpp:79 does not compile as written).  en_coeff_d2p: the
+     * expression of admm.cpp:20 with its trailing comment removed.  The reference has no executable form of either, so
+     * they are pinned against Eigen evaluating these expressions over the reference's types (oracle/ref_terms_shim.cpp). */
+    int en_uref, en_coeff_d2p;
+    const REAL *R;         /* nu */
+    const REAL *coeff_d2p; /* nx x nu (types.hpp:33) */
 } SUF(OracleProblem);
 
 typedef struct SUF(OracleWork)
@@ -52,6 +60,7 @@ typedef struct SUF(OracleWork)
     REAL primal_residual_state, primal_residual_input;
     REAL dual_residual_state, dual_residual_input;
     int status, iter;
+    const REAL *Uref; /* nu x (N-1) (types.hpp:93); read only when en_uref */
 } SUF(OracleWork);
 
 /*
@@ -211,8 +220,18 @@ void SUF(oracle_update_linear_cost)(const SUF(OracleProblem) * P, SUF(OracleWork
     const int nx = P->nx, nu = P->nu, N = P->N;
     const int nxt = nx * N, nut = nu * (N - 1);
     const REAL rho = P->rho;
-    for (int e = 0; e < nut; e++)
-        W->r[e] = ST(-rho * (W->znew[e] - W->y[e])); /* :80 */
+    if (P->en_uref)
+    {
+        /* r = -(Uref.array().colwise() * R.array());  r.noalias() -= rho * (znew - y);   (cf. :81-82 for q) */
+        for (int j = 0; j < N - 1; j++)
+            for (int i = 0; i < nu; i++)
+                W->r[(size_t)j * nu + i] = ST(-(W->Uref[(size_t)j * nu + i] * P->R[i]));
+        for (int e = 0; e < nut; e++)
+            W->r[e] = ST(W->r[e] - rho * (W->znew[e] - W->y[e]));
+    }
+    else
+        for (int e = 0; e < nut; e++)
+            W->r[e] = ST(-rho * (W->znew[e] - W->y[e])); /* :80 */
     for (int j = 0; j < N; j++)                  /* :81  q(i,j) = -(Xref(i,j)*Q(i)) */
         for (int i = 0; i < nx; i++)
             W->q[(size_t)j * nx + i] = ST(-(W->Xref[(size_t)j * nx + i] * P->Q[i]));
@@ -293,6 +312,11 @@ void SUF(oracle_backward_pass_grad)(const SUF(OracleProblem) * P, SUF(OracleWork
             REAL k = SUF(dot_vec)(P->Kinf + (size_t)j * nu, ri, nu);
             pi[j] = ST(qi[j] + a - k);
         }
+        /* "+ coeff_d2p * d.col(i)" (the trailing comment of admm.cpp:20): Eigen assigns the expression above to p.col(i)
+         * first and then adds the product, evaluated into a temporary in sequential order (pinned by ref_terms_shim) */
+        if (P->en_coeff_d2p)
+            for (int j = 0; j < nx; j++)
+                pi[j] = ST(pi[j] + SUF(dot_seq)(P->coeff_d2p + j, nx, di, nu));
     }
 }
 
@@ -336,6 +360,8 @@ typedef struct SUF(OracleBatch)
     long long bound_stride_x, bound_stride_u, xref_stride; /* element stride between instances, 0 = shared */
     REAL *residuals; /* (B,4): pri_state, pri_input, dua_state, dua_input */
     int *status, *iter;
+    const REAL *Uref; /* (B, N-1, nu) or shared; may be NULL unless en_uref */
+    long long uref_stride;
 } SUF(OracleBatch);
 
 int SUF(oracle_solve_batch)(const SUF(OracleProblem) * P, SUF(OracleBatch) * Bt, int nthreads)
@@ -357,6 +383,7 @@ int SUF(oracle_solve_batch)(const SUF(OracleProblem) * P, SUF(OracleBatch) * Bt,
         W.u_min = Bt->u_min + b * Bt->bound_stride_u; W.u_max = Bt->u_max + b * Bt->bound_stride_u;
         W.x_min = Bt->x_min + b * Bt->bound_stride_x; W.x_max = Bt->x_max + b * Bt->bound_stride_x;
         W.Xref = Bt->Xref + b * Bt->xref_stride;
+        W.Uref = Bt->Uref ? Bt->Uref + b * Bt->uref_stride : 0;
         W.primal_residual_state = Bt->residuals[4 * b + 0];
         W.primal_residual_input = Bt->residuals[4 * b + 1];
         W.dual_residual_state = Bt->residuals[4 * b + 2];

@@ -5,7 +5,8 @@
 Every round draws a problem class with an exact kernel, a batch size, settings (iteration limits, termination stride,
 tolerances, bound switches), bounds (per step, some infeasible or infinite), a reference (shared / per instance / sliding
 window), a random warm workspace (with zeros and negative zeros) and a row-kernel family, runs a chain of solves and
-requires all twelve work arrays, the residuals, status and iter to equal the oracle's bit for bit."""
+requires all twelve work arrays, the residuals, status and iter to equal the oracle's bit for bit.  One round in six also
+switches on the two terms the reference ships commented out (admm.cpp:20 coeff_d2p, :79 Uref)."""
 import sys
 import time
 from pathlib import Path
@@ -85,7 +86,18 @@ while time.time() < t_end:
     else:
         x0 = rng.uniform(-0.5, 0.5, size=(B, nx)).astype(np.float32)
         st["x"][:, 0] = R(x0); sol.set_x0(x0)
+    opt = (rng.integers(2), rng.integers(2)) if (nx + nu <= 16 and rng.random() < 0.17) else (0, 0)
+    if opt[0] or opt[1]:   # the commented-out terms: any combination, shared or per-instance Uref, zeros and negative zeros in it
+        prob = dict(prob, coeff_d2p=(rng.standard_normal((nx, nu)) * 0.05).astype(np.float32), R=rng.uniform(0.2, 3.0, nu).astype(np.float32))
+        uref = (rng.standard_normal((N - 1, nu) if rng.random() < 0.5 else (B, N - 1, nu)) * 0.2).astype(np.float32)
+        uref[rng.random(uref.shape) < 0.1] = 0.0
+        uref[rng.random(uref.shape) < 0.05] = -0.0
+        sol.set_input_cost(prob["R"]); sol.set_coeff_d2p(prob["coeff_d2p"]); sol.set_uref(uref)
+        sol.set_optional_terms(opt[0], opt[1])
+        settings = dict(settings, en_uref=int(opt[0]), en_coeff_d2p=int(opt[1]))
     orc = O.Oracle(prob, "h16" if h16 else np.float32, settings)
+    if opt[0]:
+        orc.set_uref(R(uref))
     for k in range(int(rng.integers(1, 4))):
         if rng.random() < 0.6:
             st["y"][:] = 0; st["g"][:] = 0; sol.reset_dual_variables()

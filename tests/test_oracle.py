@@ -94,6 +94,82 @@ def test_oracle_bit_exact_vs_compiled_reference(oracle_mod, tinympc, dt, nx, nu,
                 assert np.array_equal(np.signbit(a[k]), np.signbit(b[k])), (settings, k, "sign of a zero")
 
 
+TERMS_CFGS = [(np.float32, 12, 4, 30), (np.float32, 4, 1, 10), (np.float32, 8, 4, 9), (np.float32, 12, 2, 11), (np.float32, 4, 2, 8),
+              (np.float32, 4, 4, 6), (np.float64, 12, 4, 10), (np.float32, 16, 8, 10), (np.float32, 32, 16, 50)]
+
+
+@pytest.mark.parametrize("dt,nx,nu,N", TERMS_CFGS)
+def test_optional_terms_bit_exact_vs_eigen(oracle_mod, tinympc, dt, nx, nu, N):
+    """The two terms the reference comments out (admm.cpp:20 coeff_d2p, :79 Uref), enabled in the oracle, against Eigen
+    evaluating the same expressions over the reference's types (oracle/ref_terms_shim.cpp -> oracle/_ref)."""
+    import ctypes as C
+    O = oracle_mod
+    suf = "f32" if dt == np.float32 else "f64"
+    path = O.HERE / "_ref" / f"libtinympc_terms_{suf}_{nx}_{nu}_{N}.so"
+    if not path.exists():
+        pytest.skip("oracle/_ref not built here (needs /root/reference)")
+    lib = C.CDLL(str(path))
+    ct = C.c_float if dt == np.float32 else C.c_double
+    P = C.POINTER(ct)
+    lib.terms_backward_pass_grad.argtypes, lib.terms_backward_pass_grad.restype = [P] * 9, None
+    lib.terms_input_cost.argtypes, lib.terms_input_cost.restype = [ct] + [P] * 5, None
+    rng = np.random.default_rng(7 * nx + nu)
+    pr = tinympc.problems
+    prob = dict(pr.quadrotor(20, N) if (nx, nu) == (12, 4) else pr.random_system(nx, nu, N, seed=nx * 100 + nu, riccati=O.riccati))
+    prob["coeff_d2p"] = rng.standard_normal((nx, nu)) * 0.3
+    prob["R"] = rng.uniform(0.5, 3.0, nu)
+    B = 4
+    st = O.new_state(B, nx, nu, N, dt)
+    for k in STATE_ORDER:
+        st[k][:] = (rng.standard_normal(st[k].shape) * 0.4).astype(dt)
+        st[k][rng.random(st[k].shape) < 0.08] = 0.0
+        st[k][rng.random(st[k].shape) < 0.08] = -0.0
+    uref = (rng.standard_normal((B, N - 1, nu)) * 0.2).astype(dt)
+    uref[rng.random(uref.shape) < 0.1] = 0.0
+    uref[0] = -0.0
+    xref = np.zeros((N, nx), dt)
+    xmn, xmx, umn, umx = pr.bounds_arrays(prob, dt)
+    orc = O.Oracle(prob, dt, dict(en_uref=1, en_coeff_d2p=1))
+    orc.set_uref(uref)
+    a = O.copy_state(st)
+    orc.step("update_linear_cost", a, xmn, xmx, umn, umx, xref)
+    cm = lambda m: np.ascontiguousarray(np.asarray(m, dt).T).ravel()
+    ptr = lambda v: v.ctypes.data_as(P)
+    Rv = np.ascontiguousarray(prob["R"], dt)
+    for b in range(B):
+        r = np.zeros((N - 1, nu), dt)
+        lib.terms_input_cost(ct(prob["rho"]), ptr(uref[b]), ptr(Rv), ptr(st["znew"][b]), ptr(st["y"][b]), ptr(r))
+        assert np.array_equal(r, a["r"][b]) and np.array_equal(np.signbit(r), np.signbit(a["r"][b]))
+    a = O.copy_state(st)
+    orc.step("backward_pass_grad", a, xmn, xmx, umn, umx, xref)
+    mats = [cm(prob[k]) for k in ("Kinf", "Quu_inv", "AmBKt", "Bdyn", "coeff_d2p")]
+    for b in range(B):
+        p, d = st["p"][b].copy(), st["d"][b].copy()
+        lib.terms_backward_pass_grad(*[ptr(m) for m in mats], ptr(st["q"][b]), ptr(st["r"][b]), ptr(p), ptr(d))
+        for k, v in (("p", p), ("d", d)):
+            assert np.array_equal(v, a[k][b]) and np.array_equal(np.signbit(v), np.signbit(a[k][b])), k
+    # switched off (the default) the oracle is the reference: identical to an oracle that never heard of the terms
+    off, base = O.copy_state(st), O.copy_state(st)
+    o2 = O.Oracle(prob, dt, dict(max_iter=4, abs_pri_tol=0, abs_dua_tol=0))
+    o2.set_uref(uref)
+    o2.solve(off, xmn, xmx, umn, umx, xref)
+    plain = {k: v for k, v in prob.items() if k not in ("coeff_d2p",)}
+    O.Oracle(plain, dt, dict(max_iter=4, abs_pri_tol=0, abs_dua_tol=0)).solve(base, xmn, xmx, umn, umx, xref)
+    assert all(np.array_equal(off[k], base[k]) for k in STATE_ORDER)
+    # and a solve with both terms on differs from it (the terms are live) while a zero Uref / zero coeff_d2p changes no value
+    on = O.copy_state(st)
+    o3 = O.Oracle(prob, dt, dict(max_iter=4, abs_pri_tol=0, abs_dua_tol=0, en_uref=1, en_coeff_d2p=1))
+    o3.set_uref(uref)
+    o3.solve(on, xmn, xmx, umn, umx, xref)
+    assert not np.array_equal(on["u"], base["u"])
+    zero = dict(prob, coeff_d2p=np.zeros((nx, nu)))
+    z = O.copy_state(st)
+    o4 = O.Oracle(zero, dt, dict(max_iter=4, abs_pri_tol=0, abs_dua_tol=0, en_uref=1, en_coeff_d2p=1))
+    o4.set_uref(np.zeros((N - 1, nu), dt))
+    o4.solve(z, xmn, xmx, umn, umx, xref)
+    assert all(np.array_equal(z[k], base[k]) for k in STATE_ORDER)  # == : +0 and -0 compare equal
+
+
 def test_riccati_oracle_vs_reference_codegen(oracle_mod):
     """oracle_riccati (codegen.cpp:254-292 restated) against the cache the reference's tiny_codegen() emitted."""
     O = oracle_mod

@@ -47,12 +47,13 @@ def _floor(name, prob, ref):
     return max(float(np.max(np.abs(ref))), 1.0)
 
 
-def yardstick(O, prob, settings, pre, xref, bnds):
+def yardstick(O, prob, settings, pre, xref, bnds, uref=None):
     """fp64 oracle (== the reference's fp64 build) on the same live-in: the intrinsic rounding spread."""
     st = {k: (v.astype(np.float64) if v.dtype == np.float32 else v.copy()) for k, v in pre.items()}
     # a yardstick, not a parity claim: the fp64 restatement is accepted for every dimension
-    O.Oracle(prob, np.float64, settings, allow_unpinned_dims=True).solve(st, *[np.asarray(b, np.float64) for b in bnds],
-                                               np.asarray(xref, np.float64), nthreads=8)
+    orc = O.Oracle(prob, np.float64, settings, allow_unpinned_dims=True)
+    orc.set_uref(uref)
+    orc.solve(st, *[np.asarray(b, np.float64) for b in bnds], np.asarray(xref, np.float64), nthreads=8)
     return st
 
 
@@ -1196,3 +1197,155 @@ def test_wave_kernel_other_classes(tinympc, oracle_mod, dims):
         sol.solve()
         assert_bitwise(sol.get_state(), st, f"wave {dims} k={k}")
     sol.close()
+
+
+OPT_CASES = {"quad30": lambda pr: pr.quadrotor(20, 30), "quad45": lambda pr: pr.quadrotor(20, 45), "cartpole": lambda pr: pr.cartpole(10),
+             "dims_8_4_9": lambda pr: pr.random_system(8, 4, 9, seed=5), "dims_12_2_11": lambda pr: pr.random_system(12, 2, 11, seed=6)}
+
+
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("case", list(OPT_CASES))
+def test_optional_terms_vs_oracle(tinympc, oracle_mod, case, exact):
+    """The two terms the reference ships commented out (admm.cpp:20 "+ coeff_d2p * d", admm.cpp:79 Uref), switched on:
+    fused solve chain and the two step functions they live in, against the oracle (itself pinned against Eigen in
+    tests/test_oracle.py) — bitwise in exact arithmetic, fp64-yardstick in fma arithmetic; per-instance and shared Uref;
+    fp16 storage; switching them off again restores the default kernels and the reference's results."""
+    O, pr = oracle_mod, tinympc.problems
+    prob = dict(OPT_CASES[case](pr))
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    rng = np.random.default_rng(nx * 7 + nu)
+    prob["coeff_d2p"] = (rng.standard_normal((nx, nu)) * 0.02).astype(np.float32)
+    prob["R"] = rng.uniform(0.5, 2.0, nu).astype(np.float32)
+    B = 41
+    bnds = pr.bounds_arrays(prob)
+    x0 = (rng.uniform(-0.3, 0.3, (B, nx)) * (0.2 if case == "cartpole" else 1.0)).astype(np.float32)
+    xref = (rng.standard_normal((B, N, nx)) * 0.05).astype(np.float32)
+    umax = float(np.max(bnds[3]))
+    settings = dict(O.DEFAULT_SETTINGS, max_iter=30, check_termination=2, en_uref=1, en_coeff_d2p=1)
+    base = {k: v for k, v in settings.items() if not k.startswith("en_u") and not k.startswith("en_c")}
+    for storage, shared in ((32, False), (32, True), (16, False)):
+        R16 = O.round_h16 if storage == 16 else (lambda a: a)
+        uref = (rng.uniform(-0.3, 0.3, ((N - 1, nu) if shared else (B, N - 1, nu))) * umax).astype(np.float32)
+        uref[..., 0, :] = 0.0
+        sol = tinympc.TinyBatchSolver(prob, B, settings=base)
+        sol.select_kernel(2 if exact else 3)
+        sol.set_storage(storage)
+        sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
+        default_kernel = sol.kernel_name()
+        sol.set_optional_terms(True, True)
+        with pytest.raises(tinympc.TinyBatchError):  # enabled but R / Uref / coeff_d2p not given yet
+            sol.solve()
+        sol.set_input_cost(prob["R"]); sol.set_coeff_d2p(prob["coeff_d2p"]); sol.set_uref(uref)
+        assert sol.kernel_name().startswith("rowstream"), sol.kernel_name()
+        dt = "h16" if storage == 16 else np.float32
+        orc = O.Oracle(prob, dt, settings)
+        orc.set_uref(R16(uref))
+        st = O.new_state(B, nx, nu, N); st["x"][:, 0] = R16(x0)
+        bn = tuple(R16(b) for b in bnds)
+        for k in range(3):
+            pre = O.copy_state(st)
+            orc.solve(st, *bn, R16(xref), nthreads=8)
+            sol.solve()
+            got = sol.get_state()
+            what = f"optional terms {case} {sol.kernel_name()} shared={shared} k={k}"
+            if exact:
+                assert_bitwise(got, st, what)
+            else:
+                ref64 = yardstick(O, prob, settings, pre, R16(xref), bn, uref=R16(uref)) if storage == 32 else None
+                if storage == 32:
+                    compare_states(got, st, prob, what, ref64=ref64, ct=2)
+                sol.set_state(st)  # continue the chain from the oracle's state
+        assert np.abs(st["u"]).max() > 0 and st["iter"].max() > 1
+        # the two step functions the terms live in, on a random workspace
+        for k in STATE_ORDER:
+            st[k][:] = R16((rng.standard_normal(st[k].shape) * 0.3).astype(np.float32))
+        for fn in ("update_linear_cost", "backward_pass_grad"):
+            sol.set_state(st)
+            orc.step(fn, st, *bn, R16(xref))
+            getattr(sol, fn)()
+            got = sol.get_state()
+            for k in STATE_ORDER:
+                if exact:
+                    assert np.array_equal(got[k], st[k]) and np.array_equal(np.signbit(got[k]), np.signbit(st[k])), (case, fn, k, storage)
+                elif storage == 32:
+                    assert np.max(np.abs(got[k].astype(np.float64) - st[k])) <= 2e-5 * max(1.0, float(np.abs(st[k]).max())), (case, fn, k)
+        # the terms are live: the same solve without them gives different inputs
+        st2 = O.new_state(B, nx, nu, N); st2["x"][:, 0] = R16(x0)
+        ref_on, ref_off = O.copy_state(st2), O.copy_state(st2)
+        orc.solve(ref_on, *bn, R16(xref), nthreads=8)
+        O.Oracle(prob, dt, base).solve(ref_off, *bn, R16(xref), nthreads=8)
+        assert not np.array_equal(ref_on["u"], ref_off["u"])
+        # switched off again: default kernel, the reference's results
+        sol.set_optional_terms(False, False)
+        assert sol.kernel_name() == default_kernel
+        sol.reset_workspace(); sol.set_x0(x0)
+        sol.solve()
+        if exact:
+            assert_bitwise(sol.get_state(), ref_off, f"{case} terms switched off again")
+        sol.close()
+
+
+def test_optional_terms_closed_loop_native_and_errors(tinympc, oracle_mod):
+    """Optional terms in the closed loop (graph replay == step by step), through the reference's own names (TinySolver
+    members R, Uref, coeff_d2p become live), and the refusals: classes without a row kernel and the MFMA variant."""
+    O, pr = oracle_mod, tinympc.problems
+    prob = dict(pr.quadrotor(20, 30))
+    nx, nu, N = 12, 4, 30
+    rng = np.random.default_rng(3)
+    prob["coeff_d2p"] = (rng.standard_normal((nx, nu)) * 0.02).astype(np.float32)
+    B = 19
+    uref = rng.uniform(-0.1, 0.1, (B, N - 1, nu)).astype(np.float32)
+    x0, table, start = pr.tracking_batch(B, N, seed=4)
+    settings = dict(O.DEFAULT_SETTINGS, max_iter=20)
+
+    def make():
+        s = tinympc.TinyBatchSolver(prob, B, settings=settings)
+        s.set_bounds(*pr.bounds_arrays(prob)); s.set_xref_window(table, start); s.set_x0(x0)
+        s.set_input_cost(prob["R"]); s.set_coeff_d2p(prob["coeff_d2p"]); s.set_uref(uref); s.set_optional_terms(True, True)
+        return s
+    a, b = make(), make()
+    a.mpc_run_async(4, 1); a.synchronize()
+    for _ in range(4):
+        b.mpc_step_async(1)
+    b.synchronize()
+    assert_bitwise(a.get_state(), b.get_state(), "optional terms: graph replay vs step by step")
+    assert np.array_equal(a.get_x0(), b.get_x0())
+    # ... and the first of those solves is the oracle's
+    c = make(); c.solve()
+    orc = O.Oracle(prob, np.float32, dict(settings, en_uref=1, en_coeff_d2p=1)); orc.set_uref(uref)
+    st = O.new_state(B, nx, nu, N); st["x"][:, 0] = x0
+    orc.solve(st, *pr.bounds_arrays(prob), pr.expand_windows(table, start, N), nthreads=8)
+    assert_bitwise(c.get_state(), st, "optional terms with a window reference")
+    # MFMA variant and classes beyond 16 lanes refuse
+    with pytest.raises(tinympc.TinyBatchError, match="optional"):
+        c.select_kernel(1); c.solve()
+    for s in (a, b, c):
+        s.close()
+    big = pr.random_system(32, 16, 50)
+    s = tinympc.TinyBatchSolver(big, 3, settings=settings)
+    s.set_bounds(*pr.bounds_arrays(big)); s.set_xref(np.zeros((50, 32), np.float32)); s.set_x0(np.zeros((3, 32), np.float32))
+    s.set_input_cost(big["R"]); s.set_coeff_d2p(np.zeros((32, 16), np.float32)); s.set_uref(np.zeros((49, 16), np.float32))
+    s.set_optional_terms(True, False)
+    with pytest.raises(tinympc.TinyBatchError, match="optional"):
+        s.solve()
+    s.set_optional_terms(False, False)
+    s.solve()
+    s.close()
+    # the reference's own names: TinySolver members R, Uref, coeff_d2p
+    from accelerated_tinympc_amd import native
+    ns = native.NativeSolver(prob, settings)
+    try:
+        ns.set_optional_terms(True, True)
+        ns.a["x"][0] = x0[0]; ns.a["Xref"][:] = table[:N]; ns.a["Uref"][:] = uref[0]
+        for k, v in zip(("x_min", "x_max", "u_min", "u_max"), pr.bounds_arrays(prob)):
+            ns.a[k][:] = v
+        orc.set_uref(uref[0])
+        st = O.new_state(1, nx, nu, N); st["x"][0, 0] = x0[0]
+        for k in range(2):
+            rc = ns.tiny_solve()
+            ref_rc = orc.solve(st, *pr.bounds_arrays(prob), table[:N])
+            assert rc == ref_rc
+            for name in STATE_ORDER:
+                assert np.array_equal(ns.a[name], st[name][0]), (k, name)
+    finally:
+        ns.set_optional_terms(False, False)
