@@ -202,7 +202,7 @@ def main():
     value = total_solves / dt
     # the opt-in fma-chain arithmetic of the same kernel, for reference (not the headline: see DESIGN.md §3)
     fast = None
-    if rank == 0 and not args.kernel and sol.kernel_name().startswith("rowlane"):
+    if rank == 0 and world == 1 and not args.kernel and sol.kernel_name().startswith("rowlane"):
         sol.select_kernel(3)
         for _ in range(2):
             step()
@@ -221,7 +221,7 @@ def main():
     # the state staying on chip between solves (tiny_batch_mpc_run_async).
     # Reported as an extra; `value` stays the cold-start solve rate above.
     closed = None
-    if rank == 0 and not args.kernel and not args.no_closed_loop:
+    if rank == 0 and world == 1 and not args.kernel and not args.no_closed_loop:
         try:
             sol.reset_workspace()
             sol._check(lib.tiny_batch_set_x0_device(h, C.c_void_p(d_x0.data_ptr())))
@@ -244,7 +244,7 @@ def main():
     # few instances that need 2-4x the mean iteration count — overlaps the head of the next instead of leaving CUs idle.
     # Reported as an extra; `value` and the roofline above stay the plain one-launch-after-another numbers.
     pipelined = None
-    if rank == 0 and not args.kernel and not args.no_closed_loop:
+    if rank == 0 and world == 1 and not args.kernel and not args.no_closed_loop:
         sols, streams = [], [torch.cuda.Stream(), torch.cuda.Stream()]
         try:
             for strm in streams:
@@ -323,7 +323,7 @@ def main():
             line["closed_loop"] = closed
         if pipelined is not None:
             line["pipelined_batches"] = pipelined
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # rank 0 at N=1 only: the other ranks of a multi-GPU run would sit in the barrier
             line["cpu_baseline"] = cpu_baseline(prob, pr)
         print(json.dumps(line), flush=True)
     sol.close()

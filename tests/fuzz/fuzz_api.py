@@ -43,12 +43,22 @@ while time.time() < t_end:
     sol.set_bounds(*bnds); sol.set_xref(xref)
     h16 = False
     R = lambda a: a
-    orc = O.Oracle(prob, np.float32, settings)
+    # the two optional terms (commented out in the reference): data always present, switched on and off at random
+    prob = dict(prob, coeff_d2p=(rng.standard_normal((nx, nu)) * 0.03).astype(np.float32), R=rng.uniform(0.3, 2.0, nu).astype(np.float32))
+    uref = (rng.standard_normal((N - 1, nu)) * 0.1).astype(np.float32)
+    sol.set_input_cost(prob["R"]); sol.set_coeff_d2p(prob["coeff_d2p"]); sol.set_uref(uref)
+    terms = (0, 0)
+
+    def new_oracle():
+        o = O.Oracle(prob, "h16" if h16 else np.float32, dict(settings, en_uref=terms[0], en_coeff_d2p=terms[1]))
+        o.set_uref(R(uref))
+        return o
+    orc = new_oracle()
     st = O.new_state(B, nx, nu, N)
     history = []
     for _ in range(int(rng.integers(4, 14))):
         op = rng.choice(["set_x0", "reset_dual", "reset_ws", "set_array", "set_status", "switch", "solve", "solve", "read", "get_array",
-                         "storage", "bounds", "xref"])
+                         "storage", "bounds", "xref", "terms", "uref"])
         history.append(str(op)); ops_done += 1
         if op == "set_x0":
             x0 = rng.uniform(-0.5, 0.5, size=(B, nx)).astype(np.float32)
@@ -69,6 +79,8 @@ while time.time() < t_end:
             sol.set_status(st["iter"], st["status"], st["residuals"])
         elif op == "switch":
             v = int(rng.choice([0, 2, 1, 2]))
+            if v == 1 and (terms[0] or terms[1]):
+                v = 2
             try:
                 sol.select_kernel(v)
                 if v != 1:
@@ -91,10 +103,21 @@ while time.time() < t_end:
             h16 = not h16
             sol.set_storage(16 if h16 else 32)
             R = O.round_h16 if h16 else (lambda a: a)
-            orc = O.Oracle(prob, "h16" if h16 else np.float32, settings)
+            orc = new_oracle()
             for k in O.STATE_ORDER + ("residuals", "status", "iter"):
                 st[k][:] = 0
             history[-1] = f"storage->{16 if h16 else 32}"
+        elif op == "terms":
+            terms = (int(rng.integers(2)), int(rng.integers(2)))
+            if sol.kernel_name().startswith("stream"):
+                sol.select_kernel(2)   # the MFMA variant refuses the terms
+            sol.set_optional_terms(*terms)
+            orc = new_oracle()
+            history[-1] = f"terms->{terms} ({sol.kernel_name()})"
+        elif op == "uref":
+            uref = (rng.standard_normal((N - 1, nu) if rng.random() < 0.5 else (B, N - 1, nu)) * 0.1).astype(np.float32)
+            sol.set_uref(uref)
+            orc = new_oracle()
         elif op == "bounds":
             sc = rng.uniform(0.2, 1.0)
             bnds = tuple((a * sc).astype(np.float32) for a in pr.bounds_arrays(prob))
