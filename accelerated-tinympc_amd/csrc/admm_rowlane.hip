@@ -33,8 +33,10 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
 {
     const int lane = threadIdx.x;
     const int r16 = lane & 15;
-    const int inst = blockIdx.x * 4 + (lane >> 4);
-    const bool valid = inst < P.batch;
+    // dispatch order: workgroups start in index order, so order[] decides which instance groups start first
+    const int grp = P.order ? P.order[blockIdx.x] : (int)blockIdx.x;
+    const int inst = grp * 4 + (lane >> 4);
+    const bool valid = (unsigned)inst < (unsigned)P.batch; // also rejects a negative entry of a caller-supplied order
     const bool is_x = r16 < NX;
     const bool is_u = (r16 >= NX) && (r16 < NX + NU);
     const float rho = P.rho;

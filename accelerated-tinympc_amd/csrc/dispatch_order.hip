@@ -1,0 +1,93 @@
+// dispatch_order.hip — longest-first dispatch for the register-resident row kernel (tiny_batch_set_dispatch).
+//
+// Iteration counts are uneven (a few instances need 3-4x the mean) and a launch of B/4 waves over 2 048 wave slots is only a
+// handful of rounds, so waves that start late and run long leave most of the chip idle at the end of the launch.  Workgroups
+// start in index order: letting workgroup b solve instance group order[b], with the groups sorted by a PREDICTED iteration
+// count (longest first), shortens that tail.  The predictor needs no history: it is the largest primal residual
+// |[x;u] - clip([x;u] + [g;y])| of ONE forward sweep from the current workspace (how far the unconstrained LQR rollout is
+// from the box), computed here in fma arithmetic — a hint, the solve itself is untouched and its results do not depend
+// on the order.  Cost: about half an ADMM iteration per instance plus a bucket sort of B/4 keys.
+#include "rowlane_math.h"
+
+namespace tinympc
+{
+
+template <int NX, int NU, bool H16>
+__global__ __launch_bounds__(WAVE) void dispatch_key_kernel(const RowParams P, float *__restrict__ key)
+{
+    const int lane = threadIdx.x, r16 = lane & 15;
+    const int inst = blockIdx.x * 4 + (lane >> 4);
+    const bool valid = inst < P.batch;
+    const int inst_a = valid ? inst : P.batch - 1; // padding rows of the last group read a valid instance
+    const bool is_x = r16 < NX, is_u = (r16 >= NX) && (r16 < NX + NU);
+    const int N = P.N;
+    const int rowbase = (inst_a * N) * 16 + r16;
+    const bool cold = P.cold_start != 0, zdual = cold || (P.duals_zero != 0);
+    RowGains<NX, NU> G;
+    G.load(P.mats, r16); // fma gains
+    float s = ldw<H16>(P.xu, rowbase), pri = 0.f;
+    for (int i = 0; i < N; i++)
+    {
+        const int o = rowbase + i * 16;
+        float sv, xn = 0.f;
+        if (i < N - 1) lqr_step<NX, NU, false, H16>(G, is_x, is_u, s, cold ? 0.f : ldw<H16>(P.pd, o), sv, xn);
+        else sv = is_x ? s : 0.f;
+        const float2 lh = ld_bounds<H16>(P.bounds, i * 16 + r16);
+        const float a = zdual ? 0.f : ldw<H16>(P.gy, o);
+        pri = fmaxf(pri, fabsf(sv - __builtin_amdgcn_fmed3f(sv + a, lh.x, lh.y)));
+        s = xn;
+    }
+    pri = (valid && (is_x || is_u)) ? pri : 0.f;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) pri = fmaxf(pri, __shfl_xor(pri, m));
+    if (lane == 0) key[blockIdx.x] = pri;
+}
+
+// order[] = the n groups sorted by key, largest first: counting sort over 2 048 buckets = sign-less float bits >> 20 (exponent
+// and three mantissa bits; monotonic for the non-negative keys).  One workgroup; the order inside a bucket is arbitrary.
+constexpr int NBUCKET = 2048;
+__global__ __launch_bounds__(1024) void dispatch_order_kernel(const float *__restrict__ key, int *__restrict__ order, int n)
+{
+    __shared__ int cnt[NBUCKET], sa[NBUCKET], sb[NBUCKET];
+    const int t = threadIdx.x;
+    auto bucket = [](float k) { return (int)((__builtin_bit_cast(unsigned, k) & 0x7fffffffu) >> 20); };
+    for (int b = t; b < NBUCKET; b += 1024) cnt[b] = 0;
+    __syncthreads();
+    for (int g = t; g < n; g += 1024) atomicAdd(&cnt[bucket(key[g])], 1);
+    __syncthreads();
+    // inclusive scan over the buckets in DESCENDING key order (index r = NBUCKET-1-b)
+    for (int r = t; r < NBUCKET; r += 1024) sa[r] = cnt[NBUCKET - 1 - r];
+    __syncthreads();
+    int *src = sa, *dst = sb;
+    for (int d = 1; d < NBUCKET; d <<= 1)
+    {
+        for (int r = t; r < NBUCKET; r += 1024) dst[r] = src[r] + (r >= d ? src[r - d] : 0);
+        __syncthreads();
+        int *tmp = src; src = dst; dst = tmp;
+    }
+    // exclusive offset of bucket b, reusing cnt[] as the running cursor
+    for (int b = t; b < NBUCKET; b += 1024)
+    {
+        const int r = NBUCKET - 1 - b;
+        dst[b] = src[r] - cnt[b]; // dst is free now
+    }
+    __syncthreads();
+    for (int g = t; g < n; g += 1024) order[atomicAdd(&dst[bucket(key[g])], 1)] = g;
+}
+
+hipError_t launch_dispatch_order(int nx, int nu, bool h16, const RowParams &P, float *key, int *order, hipStream_t stream)
+{
+    const int ngroups = (P.batch + 3) / 4;
+#define TINY_KEY_DISPATCH(NX, NU)                                                                                      \
+    if (nx == NX && nu == NU)                                                                                          \
+    {                                                                                                                  \
+        if (h16) hipLaunchKernelGGL((dispatch_key_kernel<NX, NU, true>), dim3(ngroups), dim3(WAVE), 0, stream, P, key); \
+        else hipLaunchKernelGGL((dispatch_key_kernel<NX, NU, false>), dim3(ngroups), dim3(WAVE), 0, stream, P, key);   \
+        hipLaunchKernelGGL(dispatch_order_kernel, dim3(1), dim3(1024), 0, stream, key, order, ngroups);                \
+        return hipGetLastError();                                                                                      \
+    }
+    TINY_FOR_EACH_ROWDIMS(TINY_KEY_DISPATCH)
+    return hipErrorInvalidValue;
+}
+
+} // namespace tinympc

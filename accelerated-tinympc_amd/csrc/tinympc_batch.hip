@@ -253,6 +253,10 @@ struct TinyBatch
     std::vector<float> Rcost, coeff_d2p; // R [nu], coeff_d2p [nx x nu] column-major
     InputArr in_uref;                    // [batch or 1][N-1][nu]
     float *r_uref = nullptr;             // ROW derived: [batch_pad4 or 1][N][rw], Uref on the u rows
+    const int *order_dev = nullptr;      // caller-owned dispatch order of the instance groups (tiny_batch_set_dispatch_order_device)
+    int dispatch_mode = 0;               // tiny_batch_set_dispatch: 0 in index order, 1 longest first by the predicted iteration count
+    float *key_buf = nullptr;            // [groups] predictor of dispatch_order.hip
+    int *order_buf = nullptr;            // [groups] its sorted order
     bool derived_dirty[2] = {true, true};
     float *t_xref = nullptr, *t_bnd[4] = {};              // TILE derived
     float *r_xref = nullptr, *r_bounds = nullptr;         // ROW derived
@@ -744,6 +748,7 @@ void fill_row_params(TinyBatch *tb, RowParams &P, bool exact)
     P.uref = tb->en_uref ? tb->r_uref : nullptr;
     P.uref_inst_stride = (tb->in_uref.set && !tb->in_uref.shared) ? (unsigned)(tb->N * tb->rw) : 0u;
     P.en_d2p = tb->en_d2p ? 1 : 0;
+    P.order = tb->order_dev;
     P.res = tb->res; P.status = tb->status; P.iter = tb->iter; P.n_unsolved = tb->n_unsolved;
     P.mpc_steps = 1; P.window_advance = 0; P.u0_traj = nullptr; P.x0buf = tb->x0buf;
 }
@@ -805,6 +810,11 @@ int prepare_solve(TinyBatch *tb, int *variant)
     int v = 0;
     TRY(resolve_variant(tb, &v));
     if (tb->gains_dirty) TRY(pack_gains(tb));
+    if (tb->dispatch_mode == 1 && !tb->order_buf)
+    {
+        TRY(dev_alloc_zero(&tb->key_buf, (size_t)tb->bpad4 / 4));
+        TRY(dev_alloc_zero((float **)&tb->order_buf, (size_t)tb->bpad4 / 4));
+    }
     {
         const int layout = (v == VAR_STREAM) ? LAYOUT_TILE : LAYOUT_ROW;
         TRY(ensure_layout(tb, layout));
@@ -821,11 +831,24 @@ int prepare_solve(TinyBatch *tb, int *variant)
 }
 
 // the stream operations of one solve: counter reset + kernel launch (capturable)
+constexpr int kDispatchMinGroups = 4096; // two rounds of waves on 256 CUs x 4 SIMDs x 2 waves
+
 int enqueue_solve(TinyBatch *tb, int v, bool record_events)
 {
     const int layout = (v == VAR_STREAM) ? LAYOUT_TILE : LAYOUT_ROW;
     HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, sizeof(int), tb->stream));
-    if (record_events) HIP_TRY(hipEventRecord(tb->ev0, tb->stream));
+    // longest-first dispatch (dispatch_order.hip): predictor sweep + bucket sort ahead of the register-resident row kernel;
+    // pays off only when the launch is several rounds of waves deep
+    const bool predicted_order = layout == LAYOUT_ROW && tb->dispatch_mode == 1 && !tb->order_dev && row_family(tb) == 0 &&
+                                 tb->bpad4 / 4 >= kDispatchMinGroups && tb->max_iter > 1;
+    if (predicted_order)
+    {
+        RowParams K;
+        fill_row_params(tb, K, false); // fma gains
+        hipError_t ek = launch_dispatch_order(tb->nx, tb->nu, tb->h16, K, tb->key_buf, tb->order_buf, tb->stream);
+        if (ek != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(ek));
+    }
+    if (record_events) HIP_TRY(hipEventRecord(tb->ev0, tb->stream)); // the events bracket the solve kernel itself
     hipError_t e;
     if (layout == LAYOUT_TILE)
     {
@@ -855,6 +878,7 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
     {
         RowParams P;
         fill_row_params(tb, P, v == VAR_ROW_EXACT);
+        if (predicted_order) P.order = tb->order_buf;
         const int fam = row_family(tb);
         e = fam == 0   ? launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
             : fam == 1 ? launch_admm_rowloop(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
@@ -969,6 +993,7 @@ void tiny_batch_destroy(TinyBatch *tb)
     free_layout(tb, LAYOUT_ROW);
     (void)hipFree(tb->in_xref.dev);
     (void)hipFree(tb->in_uref.dev); (void)hipFree(tb->r_uref);
+    (void)hipFree(tb->key_buf); (void)hipFree(tb->order_buf);
     for (int k = 0; k < 4; k++) { (void)hipFree(tb->in_bnd[k].dev); (void)hipFree(tb->t_bnd[k]); }
     (void)hipFree(tb->t_xref); (void)hipFree(tb->r_xref); (void)hipFree(tb->r_bounds);
     (void)hipFree(tb->tab_tile); (void)hipFree(tb->tab_row); (void)hipFree(tb->tab_row_h); (void)hipFree(tb->xref_start);
@@ -1057,6 +1082,23 @@ int tiny_batch_set_uref(TinyBatch *tb, const float *uref, int shared)
     CHECK_TB(tb); CHECK_PTR(uref);
     TRY(set_device(tb));
     TRY(store_input(tb, tb->in_uref, uref, shared != 0, tb->N - 1, tb->nu));
+    return 0;
+}
+
+int tiny_batch_set_dispatch(TinyBatch *tb, int mode)
+{
+    CHECK_TB(tb);
+    if (mode != 0 && mode != 1) return fail(TINY_BATCH_EINVAL, "tiny_batch_set_dispatch: mode must be 0 (index order) or 1 (longest first, predicted)");
+    tb->dispatch_mode = mode;
+    if (tb->graph_exec) { (void)hipGraphExecDestroy(tb->graph_exec); tb->graph_exec = nullptr; tb->graph_sig.clear(); }
+    return 0;
+}
+
+int tiny_batch_set_dispatch_order_device(TinyBatch *tb, const int *d_order)
+{
+    CHECK_TB(tb);
+    tb->order_dev = d_order;
+    if (tb->graph_exec) { (void)hipGraphExecDestroy(tb->graph_exec); tb->graph_exec = nullptr; tb->graph_sig.clear(); }
     return 0;
 }
 

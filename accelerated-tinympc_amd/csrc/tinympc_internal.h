@@ -100,6 +100,8 @@ struct RowParams
     const float *uref;           // NULL = off; [batch or 1][N][16], Uref on the u rows (row N-1 zero)
     unsigned uref_inst_stride;   // floats between instances (0 = shared)
     int en_d2p;                  // p_i += coeff_d2p * d_i
+    const int *order;            // NULL, or a permutation of the ceil(batch/4) instance groups: workgroup b solves group order[b]
+                                 // (register-resident 16-lane kernel only; results do not depend on it)
     float *res;
     int *status, *iter, *n_unsolved;
     // closed loop on chip (admm_rowlane.hip): mpc_steps > 1 runs that many MPC steps (solve; x0 <- Adyn x0 + Bdyn u0;
@@ -137,5 +139,9 @@ bool wavedims_supported(int nx, int nu);
 hipError_t launch_admm_wavestream(int nx, int nu, const RowParams &P, hipStream_t stream);
 
 hipError_t launch_admm_stream(int nxc, int nuc, const SolveParams &P, hipStream_t stream);
+
+// longest-first dispatch order of the instance groups for the register-resident row kernel (dispatch_order.hip);
+// P.mats must be the fma gains
+hipError_t launch_dispatch_order(int nx, int nu, bool h16, const RowParams &P, float *key, int *order, hipStream_t stream);
 
 } // namespace tinympc

@@ -69,6 +69,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch_enable_timing": [P, C.c_int], "tiny_batch_last_solve_ms": [P, F],
         "tiny_batch_select_kernel": [P, C.c_int], "tiny_batch_set_storage": [P, C.c_int],
         "tiny_batch_set_row_kernel": [P, C.c_int],
+        "tiny_batch_set_dispatch": [P, C.c_int], "tiny_batch_set_dispatch_order_device": [P, P],
         "tiny_batch_set_optional_terms": [P, C.c_int, C.c_int], "tiny_batch_set_input_cost": [P, F],
         "tiny_batch_set_coeff_d2p": [P, F], "tiny_batch_set_uref": [P, F, C.c_int],
         "tiny_batch_group_solve": [C.POINTER(P), C.c_int, I],
@@ -330,6 +331,14 @@ class TinyBatchSolver:
     def set_row_kernel(self, family: int):
         """0 auto, 1 rowlane (unrolled), 2 rowloop (rolled, N <= 32), 3 rowstream (state in HBM), 4 quadlane (nx=4, nu=1)."""
         self._check(self.lib.tiny_batch_set_row_kernel(self._h, family))
+
+    def set_dispatch(self, mode: int):
+        """0 = workgroups in index order, 1 = longest first by a predicted iteration count (register-resident row kernel)."""
+        self._check(self.lib.tiny_batch_set_dispatch(self._h, mode))
+
+    def set_dispatch_order_device(self, d_order_ptr):
+        """Device pointer to a permutation of the ceil(batch/4) group indices (int32), or None."""
+        self._check(self.lib.tiny_batch_set_dispatch_order_device(self._h, C.c_void_p(d_order_ptr)))
 
     def set_storage(self, bits: int):
         """32 = fp32 work arrays (default); 16 = IEEE binary16 storage with fp32 arithmetic.  Restarts the workspace."""

@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--mode", choices=["early_exit", "fixed10"], default="early_exit")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto (rowlane exact), 1 streaming, 2 rowlane exact, 3 rowlane fast")
+    ap.add_argument("--dispatch", type=int, choices=[0, 1], default=1,
+                    help="workgroup dispatch order of the row kernel: 0 index order, 1 longest first by the predicted iteration count "
+                         "(tiny_batch_set_dispatch; the predictor sweep and the sort run inside the timed region)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the warm-started closed-loop and the pipelined-batches extras (profiling runs: "
                     "its launches of the same kernel would be averaged into the per-kernel statistics)")
@@ -142,6 +145,7 @@ def main():
         sol.select_kernel(args.kernel)
     sol.set_bounds(*pr.bounds_arrays(prob))
     sol.set_xref_window(table, start)
+    sol.set_dispatch(args.dispatch)
     d_x0 = torch.from_numpy(np.ascontiguousarray(x0)).cuda()
     lib, h = sol.lib, sol._h
 
@@ -251,6 +255,7 @@ def main():
                 s2 = T.TinyBatchSolver(prob, B, device=dev_index, settings=settings)
                 s2.set_bounds(*pr.bounds_arrays(prob))
                 s2.set_xref_window(table, start)
+                s2.set_dispatch(0)  # overlapping launches already fill the tail; the predictor sweep would only add work
                 s2.set_stream(strm.cuda_stream)
                 sols.append(s2)
 
@@ -311,7 +316,9 @@ def main():
                                    f"{args.mode} (tol 1e-3, max_iter 100)" if args.mode == "early_exit" else
                                    f"quadrotor_tracking batched {B} instances per GPU, cold-start tiny_solve, fixed 10 iterations",
                        "nx": NX, "nu": NU, "N": N, "instances_per_gpu": B, "parallelism": f"batch-shard x{world}",
-                       "kernel": sol.kernel_name(), "mean_iters": agg["sum_iters"] / agg["n_instances"],
+                       "kernel": sol.kernel_name(),
+                       "dispatch": "longest first by predicted iteration count (predictor sweep + sort inside the timed region)"
+                                   if args.dispatch else "index order", "mean_iters": agg["sum_iters"] / agg["n_instances"],
                        "max_iters": agg["max_iters"], "frac_converged": agg["n_converged"] / agg["n_instances"]},
             "roofline": roof,
         }

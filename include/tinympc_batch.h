@@ -186,6 +186,17 @@ extern "C"
      * are rounded when they are stored.  Changing the precision restarts the workspace from zero, like create. */
     int tiny_batch_set_storage(TinyBatch *tb, int bits);
 
+    /* Dispatch order of the register-resident 16-lane row kernel (a launch of batch/4 workgroups is a few rounds deep and
+     * iteration counts are uneven, so what starts last decides when the launch ends; results never depend on the order).
+     * mode 0 (default): index order.  mode 1: longest first by a predicted iteration count — one fma forward sweep from the
+     * current workspace gives the largest primal residual per group of four instances, a bucket sort orders the groups;
+     * applied to launches of at least 4096 groups, a no-op elsewhere. */
+    int tiny_batch_set_dispatch(TinyBatch *tb, int mode);
+    /* The caller's own order (e.g. from the iteration counts of the previous MPC step): d_order is a device array holding a
+     * permutation of the ceil(batch/4) group indices, workgroup b solves instances 4*d_order[b] .. +3; it must stay valid
+     * until the solves that use it have finished.  NULL returns to tiny_batch_set_dispatch's mode. */
+    int tiny_batch_set_dispatch_order_device(TinyBatch *tb, const int *d_order);
+
     /* ---- the two terms the reference ships commented out, off by default ----
      * en_coeff_d2p: backward_pass_grad adds "+ coeff_d2p * d.col(i)" to p.col(i) (the trailing comment of
      * src/tinympc/admm.cpp:20; TinyCache::coeff_d2p, types.hpp:33).  en_uref: update_linear_cost computes

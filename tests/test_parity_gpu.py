@@ -94,6 +94,23 @@ def compare_states(got, ref, prob, what, ref64=None, exact=False, fixed=False, c
     return nflip
 
 
+class DevBuf:
+    """A device copy of a numpy array through the HIP runtime the library itself links (no torch in these tests)."""
+
+    def __init__(self, a):
+        import ctypes
+        self._hip = ctypes.CDLL("libamdhip64.so")
+        a = np.ascontiguousarray(a)
+        p = ctypes.c_void_p()
+        assert self._hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(a.nbytes)) == 0
+        assert self._hip.hipMemcpy(p, ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes), 1) == 0
+        self.ptr = p.value
+
+    def free(self):
+        import ctypes
+        self._hip.hipFree(ctypes.c_void_p(self.ptr))
+
+
 def make_solver(T, prob, B, settings, xref, variant="stream", bnds=None):
     """Create a solver forced onto one kernel variant; skips the test if that variant has no instantiation."""
     s = T.TinyBatchSolver(prob, B, settings=settings)
@@ -419,6 +436,21 @@ def test_full_size_properties(tinympc, oracle_mod, variant, config, B):
     b = sol.get_state()
     for k in STATE_ORDER + SCALARS:
         assert np.array_equal(a[k], b[k]), k
+    # (2b) the dispatch order is invisible in the results: longest first by the predicted iteration count (a no-op below
+    # 4096 groups and for the kernels that stream their state), then the caller's own order, here the reverse
+    sol.set_dispatch(1)
+    sol.reset_workspace(); sol.set_x0(x0); sol.solve()
+    b = sol.get_state()
+    for k in STATE_ORDER + SCALARS:
+        assert np.array_equal(a[k], b[k]), ("dispatch 1", k)
+    order = DevBuf(np.arange((B + 3) // 4, dtype=np.int32)[::-1].copy())
+    sol.set_dispatch_order_device(order.ptr)
+    sol.reset_workspace(); sol.set_x0(x0); sol.solve()
+    b = sol.get_state()
+    for k in STATE_ORDER + SCALARS:
+        assert np.array_equal(a[k], b[k]), ("reverse order", k)
+    sol.set_dispatch_order_device(None); sol.set_dispatch(0)
+    sol.synchronize(); order.free()
     # (3) invariants of the algorithm
     s = sol.settings
     assert set(np.unique(a["status"])) <= {1, 11} and a["iter"].min() >= 1 and a["iter"].max() <= s["max_iter"]
@@ -1074,6 +1106,9 @@ def test_kernel_selection_and_option_errors(tinympc):
         q17.set_storage(8)
     with pytest.raises(tinympc.TinyBatchError):
         q17.mpc_run_async(0, 0)
+    with pytest.raises(tinympc.TinyBatchError):
+        q17.set_dispatch(2)
+    q17.set_dispatch(1)                                            # accepted everywhere, acts on large rowlane launches only
     q17.close()
     q40 = tinympc.TinyBatchSolver(pr.quadrotor(20, 40), 8)         # N > 32: only the streaming row kernel
     assert q40.kernel_name().startswith("rowstream")
@@ -1349,3 +1384,40 @@ def test_optional_terms_closed_loop_native_and_errors(tinympc, oracle_mod):
                 assert np.array_equal(ns.a[name], st[name][0]), (k, name)
     finally:
         ns.set_optional_terms(False, False)
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_predicted_longest_first_dispatch(tinympc, oracle_mod, exact):
+    """tiny_batch_set_dispatch(1): the predictor sweep and the bucket sort run ahead of the register-resident kernel for
+    launches of >= 4096 groups (warm and cold workspaces, fp16 storage, a ragged last group) — results bitwise those of the
+    index-order launch, and the exact ones those of the oracle on a sample."""
+    O, pr = oracle_mod, tinympc.problems
+    prob = pr.quadrotor(20, 30)
+    B = 4 * 4096 + 3
+    x0, table, start = pr.tracking_batch(B, 30, seed=9)
+    settings = dict(O.DEFAULT_SETTINGS, max_iter=40)
+    for storage in (32, 16):
+        res = []
+        for mode in (0, 1):
+            sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+            sol.select_kernel(2 if exact else 3)
+            sol.set_storage(storage)
+            sol.set_bounds(*pr.bounds_arrays(prob)); sol.set_xref_window(table, start); sol.set_x0(x0)
+            assert sol.kernel_name().startswith("rowlane")
+            sol.set_dispatch(mode)
+            chain = []
+            for k in range(3):      # cold, then two warm-started solves (the predictor reads d, y, g of the workspace)
+                sol.solve()
+                chain.append(sol.get_state())
+                if k == 1:
+                    sol.reset_dual_variables()
+            res.append(chain)
+            sol.close()
+        for k in range(3):
+            for name in STATE_ORDER + SCALARS:
+                assert np.array_equal(res[0][k][name], res[1][k][name]), (storage, k, name)
+        if exact and storage == 32:
+            idx = np.r_[np.arange(0, B, 97), B - 3, B - 2, B - 1]
+            st = O.new_state(idx.size, 12, 4, 30); st["x"][:, 0] = x0[idx]
+            O.Oracle(prob, np.float32, settings).solve(st, *pr.bounds_arrays(prob), pr.expand_windows(table, start[idx], 30), nthreads=8)
+            assert_bitwise({k: res[1][0][k][idx] for k in STATE_ORDER + SCALARS}, st, "dispatch 1 vs oracle")
