@@ -6,7 +6,8 @@ Every round draws a problem class with an exact kernel, a batch size, settings (
 tolerances, bound switches), bounds (per step, some infeasible or infinite), a reference (shared / per instance / sliding
 window), a random warm workspace (with zeros and negative zeros) and a row-kernel family, runs a chain of solves and
 requires all twelve work arrays, the residuals, status and iter to equal the oracle's bit for bit.  One round in six also
-switches on the two terms the reference ships commented out (admm.cpp:20 coeff_d2p, :79 Uref)."""
+switches on the two terms the reference ships commented out (admm.cpp:20 coeff_d2p, :79 Uref), one in five runs under a
+random caller-supplied dispatch order."""
 import sys
 import time
 from pathlib import Path
@@ -16,6 +17,17 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import accelerated_tinympc_amd as T  # noqa: E402
 from oracle import oracle as O  # noqa: E402
+
+import ctypes  # noqa: E402
+hip = ctypes.CDLL("libamdhip64.so")  # the runtime the library links: device buffers for caller-supplied dispatch orders
+
+
+def dev_ints(a):
+    p = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(a.nbytes)) == 0
+    assert hip.hipMemcpy(p, ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes), 1) == 0
+    return p
+
 
 pr = T.problems
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -95,6 +107,12 @@ while time.time() < t_end:
         sol.set_input_cost(prob["R"]); sol.set_coeff_d2p(prob["coeff_d2p"]); sol.set_uref(uref)
         sol.set_optional_terms(opt[0], opt[1])
         settings = dict(settings, en_uref=int(opt[0]), en_coeff_d2p=int(opt[1]))
+    d_order = None
+    if rng.random() < 0.2:   # a caller-supplied dispatch order (random permutation of the groups of four) or the predicted one
+        d_order = dev_ints(rng.permutation((B + 3) // 4).astype(np.int32))
+        sol.set_dispatch_order_device(d_order.value)
+    elif rng.random() < 0.1:
+        sol.set_dispatch(1)
     orc = O.Oracle(prob, "h16" if h16 else np.float32, settings)
     if opt[0]:
         orc.set_uref(R(uref))
@@ -134,5 +152,7 @@ while time.time() < t_end:
             print(f"MISMATCH round {rounds} step function {fn} {kind} N={N} B={B} h16={h16} settings {settings}")
             sys.exit(1)
     sol.close(); rounds += 1
+    if d_order is not None:
+        hip.hipFree(d_order)
 print(f"fuzz ok: {rounds} rounds, {solves} solves, all bitwise equal to the oracle (signs of zeros included); "
       f"{overflowed} rounds left the finite range and were not compared")
