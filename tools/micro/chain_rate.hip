@@ -4,7 +4,8 @@
 //   E1  exact, products and SEQ adds interleaved in one block (each add issues >= 2 instructions after its producer)
 //   F0  fast, as built today: 12 dependent v_fmac_f32_dpp
 //   F1  fast, two accumulators (6+6) and one add        F2  fast, four accumulators (3+3+3+3) and three adds
-// Build: hipcc --offload-arch=gfx950 -O3 tools/micro/chain_rate.hip -o build/chain_rate
+//   L0/L1 the same products with the broadcast going through LDS (ds_write_b32 + 3 ds_read_b128) and plain VALU instructions
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/micro/chain_rate.hip -o build/chain_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define D(k) " row_newbcast:" #k " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
@@ -115,6 +116,31 @@ __global__ __launch_bounds__(256) void k(float *out, const float *in, int iters,
                          : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]));
             acc = t0;
         }
+        else if constexpr (MODE == 9 || MODE == 10) // broadcast through LDS instead of DPP: the row writes its 16 values, every lane reads the 12 it needs
+        {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const unsigned base = (unsigned)(size_t)pad + (threadIdx.x >> 6) * 256u;
+            const unsigned waddr = base + (threadIdx.x & 63) * 4u, raddr = base + ((threadIdx.x & 63) >> 4) * 64u;
+            f4 q0, q1, q2;
+            asm volatile("ds_write_b32 %1, %0\n s_waitcnt lgkmcnt(0)\n" ::"v"(x), "v"(waddr) : "memory");
+            asm volatile("ds_read_b128 %0, %3\n ds_read_b128 %1, %3 offset:16\n ds_read_b128 %2, %3 offset:32\n s_waitcnt lgkmcnt(0)\n"
+                         : "=&v"(q0), "=&v"(q1), "=&v"(q2) : "v"(raddr) : "memory");
+            if constexpr (MODE == 9) // 12 plain muls + 11 SEQ adds, separately rounded (-ffp-contract=off)
+            {
+                acc = q0.x * m[0];
+                acc = acc + q0.y * m[1]; acc = acc + q0.z * m[2]; acc = acc + q0.w * m[3];
+                acc = acc + q1.x * m[4]; acc = acc + q1.y * m[5]; acc = acc + q1.z * m[6]; acc = acc + q1.w * m[7];
+                acc = acc + q2.x * m[8]; acc = acc + q2.y * m[9]; acc = acc + q2.z * m[10]; acc = acc + q2.w * m[11];
+            }
+            else // 12 dependent plain fmas
+            {
+                acc = q0.x * m[0];
+                acc = __builtin_fmaf(q0.y, m[1], acc); acc = __builtin_fmaf(q0.z, m[2], acc); acc = __builtin_fmaf(q0.w, m[3], acc);
+                acc = __builtin_fmaf(q1.x, m[4], acc); acc = __builtin_fmaf(q1.y, m[5], acc); acc = __builtin_fmaf(q1.z, m[6], acc);
+                acc = __builtin_fmaf(q1.w, m[7], acc); acc = __builtin_fmaf(q2.x, m[8], acc); acc = __builtin_fmaf(q2.y, m[9], acc);
+                acc = __builtin_fmaf(q2.z, m[10], acc); acc = __builtin_fmaf(q2.w, m[11], acc);
+            }
+        }
         x = acc; // the next block broadcasts this result
     }
     out[blockIdx.x * 256 + threadIdx.x] = x + pad[(threadIdx.x + 1) & 63];
@@ -166,6 +192,8 @@ int main()
         run<6>("M  12 independent plain muls", d, in, w, 12);
         run<7>("P  12 independent mul_dpp", d, in, w, 12);
         run<8>("E2 exact shape with a halving tree", d, in, w, 23);
+        run<9>("L0 exact, broadcast through LDS (1 write, 3 b128 reads)", d, in, w, 27);
+        run<10>("L1 fast, broadcast through LDS, 12 plain fmas", d, in, w, 16);
     }
     return 0;
 }
