@@ -1416,6 +1416,27 @@ def test_predicted_longest_first_dispatch(tinympc, oracle_mod, exact):
         for k in range(3):
             for name in STATE_ORDER + SCALARS:
                 assert np.array_equal(res[0][k][name], res[1][k][name]), (storage, k, name)
+        if storage == 16:
+            # closed loop with the predicted order inside a replayed hipGraph (fp16 storage runs the unrolled kernel from a
+            # graph; fp32 keeps the state on chip and never re-dispatches) against step-by-step launches in index order
+            pair = []
+            for mode in (1, 0):
+                sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+                sol.select_kernel(2 if exact else 3)
+                sol.set_storage(16)
+                sol.set_bounds(*pr.bounds_arrays(prob)); sol.set_xref_window(table, start); sol.set_x0(x0)
+                sol.set_dispatch(mode)
+                if mode:
+                    sol.mpc_run_async(3, 1)
+                else:
+                    for _ in range(3):
+                        sol.mpc_step_async(1)
+                sol.synchronize()
+                pair.append((sol.get_state(), sol.get_x0()))
+                sol.close()
+            for name in STATE_ORDER + SCALARS:
+                assert np.array_equal(pair[0][0][name], pair[1][0][name]), ("closed loop", name)
+            assert np.array_equal(pair[0][1], pair[1][1])
         if exact and storage == 32:
             idx = np.r_[np.arange(0, B, 97), B - 3, B - 2, B - 1]
             st = O.new_state(idx.size, 12, 4, 30); st["x"][:, 0] = x0[idx]
