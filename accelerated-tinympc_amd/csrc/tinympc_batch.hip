@@ -275,6 +275,7 @@ struct TinyBatch
     size_t staging_floats = 0;
     bool duals_zero_pending = false;
     bool cold_pending = false;
+    bool x0_zero_pending = false; // reset_workspace(): x.col(0) and x0buf read as zero until a set_x0 overwrites them
     int variant = VAR_AUTO;
     int row_family_forced = -1; // tiny_batch_set_row_kernel
     bool h16 = false; // ROW-layout arrays, Xref and bounds stored as IEEE binary16 (tiny_batch_set_storage)
@@ -356,9 +357,20 @@ int launch_zero(TinyBatch *tb, float *dst, int layout, int fam, int step0, int n
     return 0;
 }
 
+// reset_workspace() zeroes x.col(0) lazily too: the usual next call is set_x0, which overwrites all of it
+int flush_x0_zero(TinyBatch *tb)
+{
+    if (!tb->x0_zero_pending) return 0;
+    TRY(launch_zero(tb, work_ptr(tb, TINY_ARR_X), tb->layout, 0, 0, 1));
+    HIP_TRY(hipMemsetAsync(tb->x0buf, 0, (size_t)tb->batch * tb->nx * sizeof(float), tb->stream));
+    tb->x0_zero_pending = false;
+    return 0;
+}
+
 // Materialise pending lazy resets (needed before anything other than a solve looks at the arrays).
 int flush_pending(TinyBatch *tb)
 {
+    TRY(flush_x0_zero(tb));
     if (tb->cold_pending)
     {
         // every work array reads as zero after reset_workspace(), except x.col(0) which carries x0
@@ -820,6 +832,7 @@ int prepare_solve(TinyBatch *tb, int *variant)
         TRY(ensure_layout(tb, layout));
         TRY(prepare_inputs(tb, layout));
     }
+    TRY(flush_x0_zero(tb)); // every solve reads x.col(0)
     if (tb->max_iter <= 0) TRY(flush_pending(tb));
     // The kernels that stream their state through HBM write p, d, v, z only in backward sweeps: a cold start that
     // converges in its first iteration (x0 at the origin) would leave those arrays unmaterialised.  Only the
@@ -1120,6 +1133,7 @@ int tiny_batch_set_x0(TinyBatch *tb, const float *x0)
 {
     CHECK_TB(tb); CHECK_PTR(x0);
     TRY(set_device(tb));
+    tb->x0_zero_pending = false; // all of x.col(0) and x0buf is overwritten
     HIP_TRY(hipMemcpyAsync(tb->x0buf, x0, (size_t)tb->batch * tb->nx * sizeof(float), hipMemcpyHostToDevice, tb->stream));
     return upload_work(tb, x0, TINY_ARR_X, 0, 1);
 }
@@ -1128,6 +1142,7 @@ int tiny_batch_set_x0_device(TinyBatch *tb, const float *d_x0)
 {
     CHECK_TB(tb); CHECK_PTR(d_x0);
     TRY(set_device(tb));
+    tb->x0_zero_pending = false; // all of x.col(0) and x0buf is overwritten
     HIP_TRY(hipMemcpyAsync(tb->x0buf, d_x0, (size_t)tb->batch * tb->nx * sizeof(float), hipMemcpyDeviceToDevice, tb->stream));
     return launch_pack(tb, d_x0, work_ptr(tb, TINY_ARR_X), tb->layout, 0, tb->batch, false, 0, 1);
 }
@@ -1316,11 +1331,10 @@ int tiny_batch_reset_workspace(TinyBatch *tb)
 {
     CHECK_TB(tb);
     TRY(set_device(tb));
-    // x.col(0) (the x0 the caller sets next) is zeroed now; everything else is zeroed lazily: the next solve
-    // reads d,v,z,y,g (and p) as zero in its first iteration and overwrites the rest, any other reader triggers the
-    // zero fill (flush_pending).
-    TRY(launch_zero(tb, work_ptr(tb, TINY_ARR_X), tb->layout, 0, 0, 1));
-    HIP_TRY(hipMemsetAsync(tb->x0buf, 0, (size_t)tb->batch * tb->nx * sizeof(float), tb->stream));
+    // Everything is zeroed lazily: the next solve reads d,v,z,y,g (and p) as zero in its first iteration and overwrites
+    // the rest, any other reader triggers the zero fill (flush_pending); x.col(0) is zeroed before the next solve unless
+    // a set_x0 overwrites it first (flush_x0_zero).
+    tb->x0_zero_pending = true;
     tb->cold_pending = true;
     tb->duals_zero_pending = false;
     return 0;
@@ -1468,6 +1482,7 @@ int tiny_batch_get_x0(TinyBatch *tb, float *x0)
 {
     CHECK_TB(tb); CHECK_PTR(x0);
     TRY(set_device(tb));
+    TRY(flush_x0_zero(tb));
     HIP_TRY(hipMemcpyAsync(x0, tb->x0buf, (size_t)tb->batch * tb->nx * sizeof(float), hipMemcpyDeviceToHost, tb->stream));
     HIP_TRY(hipStreamSynchronize(tb->stream));
     return 0;
@@ -1533,7 +1548,7 @@ int tiny_batch_set_storage(TinyBatch *tb, int bits)
     HIP_TRY(hipMemsetAsync(tb->status, 0, (size_t)tb->batch * sizeof(int), tb->stream));
     HIP_TRY(hipMemsetAsync(tb->iter, 0, (size_t)tb->batch * sizeof(int), tb->stream));
     HIP_TRY(hipMemsetAsync(tb->x0buf, 0, (size_t)tb->batch * tb->nx * sizeof(float), tb->stream));
-    tb->cold_pending = tb->duals_zero_pending = false;
+    tb->cold_pending = tb->duals_zero_pending = tb->x0_zero_pending = false;
     tb->derived_dirty[0] = tb->derived_dirty[1] = true;
     return 0;
 }
