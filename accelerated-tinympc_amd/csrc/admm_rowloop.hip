@@ -28,8 +28,9 @@ __global__ __launch_bounds__(WAVE, 3) void admm_rowloop_kernel(const RowParams P
     extern __shared__ float lds[];
     const int lane = threadIdx.x;
     const int r16 = lane & 15;
-    const int inst = blockIdx.x * 4 + (lane >> 4);
-    const bool valid = inst < P.batch;
+    const int grp = P.order ? P.order[blockIdx.x] : (int)blockIdx.x; // dispatch order (tiny_batch_set_dispatch)
+    const int inst = grp * 4 + (lane >> 4);
+    const bool valid = (unsigned)inst < (unsigned)P.batch;
     const bool is_x = r16 < NX;
     const bool is_u = (r16 >= NX) && (r16 < NX + NU);
     const int N = P.N;

@@ -850,9 +850,9 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
 {
     const int layout = (v == VAR_STREAM) ? LAYOUT_TILE : LAYOUT_ROW;
     HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, sizeof(int), tb->stream));
-    // longest-first dispatch (dispatch_order.hip): predictor sweep + bucket sort ahead of the register-resident row kernel;
+    // longest-first dispatch (dispatch_order.hip): predictor sweep + bucket sort ahead of the register-resident 16-lane kernels;
     // pays off only when the launch is several rounds of waves deep
-    const bool predicted_order = layout == LAYOUT_ROW && tb->dispatch_mode == 1 && !tb->order_dev && row_family(tb) == 0 &&
+    const bool predicted_order = layout == LAYOUT_ROW && tb->dispatch_mode == 1 && !tb->order_dev && (row_family(tb) == 0 || row_family(tb) == 1) &&
                                  tb->bpad4 / 4 >= kDispatchMinGroups && tb->max_iter > 1;
     if (predicted_order)
     {

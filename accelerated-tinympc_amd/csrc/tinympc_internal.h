@@ -101,7 +101,7 @@ struct RowParams
     unsigned uref_inst_stride;   // floats between instances (0 = shared)
     int en_d2p;                  // p_i += coeff_d2p * d_i
     const int *order;            // NULL, or a permutation of the ceil(batch/4) instance groups: workgroup b solves group order[b]
-                                 // (register-resident 16-lane kernel only; results do not depend on it)
+                                 // (register-resident 16-lane kernels only; results do not depend on it)
     float *res;
     int *status, *iter, *n_unsolved;
     // closed loop on chip (admm_rowlane.hip): mpc_steps > 1 runs that many MPC steps (solve; x0 <- Adyn x0 + Bdyn u0;

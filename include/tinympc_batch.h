@@ -186,7 +186,7 @@ extern "C"
      * are rounded when they are stored.  Changing the precision restarts the workspace from zero, like create. */
     int tiny_batch_set_storage(TinyBatch *tb, int bits);
 
-    /* Dispatch order of the register-resident 16-lane row kernel (a launch of batch/4 workgroups is a few rounds deep and
+    /* Dispatch order of the register-resident 16-lane row kernels, unrolled and rolled (a launch of batch/4 workgroups is a few rounds deep and
      * iteration counts are uneven, so what starts last decides when the launch ends; results never depend on the order).
      * mode 0 (default): index order.  mode 1: longest first by a predicted iteration count — one fma forward sweep from the
      * current workspace gives the largest primal residual per group of four instances, a bucket sort orders the groups;

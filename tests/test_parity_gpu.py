@@ -1386,8 +1386,9 @@ def test_optional_terms_closed_loop_native_and_errors(tinympc, oracle_mod):
         ns.set_optional_terms(False, False)
 
 
+@pytest.mark.parametrize("family", [0, 2])   # set_row_kernel: the unrolled and the rolled-loop register-resident kernels
 @pytest.mark.parametrize("exact", [True, False])
-def test_predicted_longest_first_dispatch(tinympc, oracle_mod, exact):
+def test_predicted_longest_first_dispatch(tinympc, oracle_mod, exact, family):
     """tiny_batch_set_dispatch(1): the predictor sweep and the bucket sort run ahead of the register-resident kernel for
     launches of >= 4096 groups (warm and cold workspaces, fp16 storage, a ragged last group) — results bitwise those of the
     index-order launch, and the exact ones those of the oracle on a sample."""
@@ -1402,8 +1403,9 @@ def test_predicted_longest_first_dispatch(tinympc, oracle_mod, exact):
             sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
             sol.select_kernel(2 if exact else 3)
             sol.set_storage(storage)
+            sol.set_row_kernel(family)
             sol.set_bounds(*pr.bounds_arrays(prob)); sol.set_xref_window(table, start); sol.set_x0(x0)
-            assert sol.kernel_name().startswith("rowlane")
+            assert sol.kernel_name().startswith("rowloop" if family == 2 else "rowlane")
             sol.set_dispatch(mode)
             chain = []
             for k in range(3):      # cold, then two warm-started solves (the predictor reads d, y, g of the workspace)
@@ -1424,6 +1426,7 @@ def test_predicted_longest_first_dispatch(tinympc, oracle_mod, exact):
                 sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
                 sol.select_kernel(2 if exact else 3)
                 sol.set_storage(16)
+                sol.set_row_kernel(family)
                 sol.set_bounds(*pr.bounds_arrays(prob)); sol.set_xref_window(table, start); sol.set_x0(x0)
                 sol.set_dispatch(mode)
                 if mode:
