@@ -11,11 +11,14 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
   bounds on, quadrotor_tracking.cpp:75-80), bounds u in [-0.5,0.5], x in [-5,5].
 One "step" = one cold-start tiny_solve() of every instance of the batch: reset_workspace (folded into the solve),
 x0 from a device buffer, per-instance reference windows gathered on the device from the trajectory table, one
-kernel launch running all ADMM iterations with per-instance early exit.  Inputs are resident in HBM before the
-timed region.  The batch shards embarrassingly across ranks (weak scaling: 65536 instances per GPU); there is no
+kernel launch running all ADMM iterations with per-instance early exit — preceded, by default (--dispatch 1), by the
+predictor sweep and bucket sort that let the launch start its longest instance groups first (tiny_batch_set_dispatch;
+part of the timed step, not of `roofline.kernel_ms`).  Inputs are resident in HBM before the timed region.  The batch shards embarrassingly across ranks (weak scaling: 65536 instances per GPU); there is no
 data-path collective — torch.distributed is used only for the barriers and the max-over-ranks of the time.
 
-Prints ONE JSON line (rank 0).  `roofline` and `cpu_baseline` are described in DESIGN.md §Measurement.
+Prints ONE JSON line (rank 0).  `roofline` and `cpu_baseline` are described in DESIGN.md §Measurement.  At N=1 the line
+also carries extras that never enter `value`: `fast_arithmetic` (the fma variant of the kernel), `closed_loop` (warm-started
+MPC steps in one launch), `pipelined_batches` (consecutive batches double-buffered on two streams).
 """
 from __future__ import annotations
 
