@@ -163,7 +163,8 @@ extern "C"
     /* ---- measurement ------------------------------------------------------------------------- */
     /* When enabled, every solve records hipEvents around its kernel launches on the stream. */
     int tiny_batch_enable_timing(TinyBatch *tb, int on);
-    /* Synchronises and returns the device time in ms of the most recent solve's kernel(s). */
+    /* Synchronises and returns the device time in ms of the most recent solve's kernel (the predictor sweep and sort of
+     * tiny_batch_set_dispatch(tb, 1) run before the first event and are not included). */
     int tiny_batch_last_solve_ms(TinyBatch *tb, float *ms);
     /* Name of the kernel variant the next solve will launch ("rowlane<12,4,30,exact>", "rowstream<12,4,fast>",
      * "stream<3,1>", with ",h16" appended under fp16 storage). */
@@ -186,10 +187,10 @@ extern "C"
      * are rounded when they are stored.  Changing the precision restarts the workspace from zero, like create. */
     int tiny_batch_set_storage(TinyBatch *tb, int bits);
 
-    /* Dispatch order of the register-resident 16-lane row kernels, unrolled and rolled (a launch of batch/4 workgroups is a few rounds deep and
-     * iteration counts are uneven, so what starts last decides when the launch ends; results never depend on the order).
-     * mode 0 (default): index order.  mode 1: longest first by a predicted iteration count — one fma forward sweep from the
-     * current workspace gives the largest primal residual per group of four instances, a bucket sort orders the groups;
+    /* Dispatch order of the register-resident 16-lane row kernels, unrolled and rolled (a launch of batch/4 workgroups is a
+     * few rounds deep and iteration counts are uneven, so what starts last decides when the launch ends; results never depend on the order).
+     * mode 0 (default): index order.  mode 1: longest first by a predicted iteration count — one fma forward sweep over the first
+     * eight horizon steps from the current workspace gives the largest primal residual per group of four instances, a bucket sort orders the groups;
      * applied to launches of at least 4096 groups, a no-op elsewhere. */
     int tiny_batch_set_dispatch(TinyBatch *tb, int mode);
     /* The caller's own order (e.g. from the iteration counts of the previous MPC step): d_order is a device array holding a
