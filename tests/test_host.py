@@ -194,3 +194,21 @@ def test_native_names_header_is_plain_c_and_matches_the_binding(tinympc, tmp_pat
         body = ref_types.read_text().split("Problem variables")[1].split("} TinyWorkspace")[0]
         ref_members = re.findall(r"^\s*(?:tiny_\w+|tinytype|int)\s+(\w+);", body, re.M)
         assert [f[0] for f in native.TinyWorkspace._fields_[3:]] == ref_members
+
+
+def test_recorded_bench_line_has_the_contract_fields():
+    """profiles/r01_bench_default_line.json is the stdout of `python bench.py` on the MI355X: the keys the driver reads."""
+    import json
+    d = json.loads((ROOT / "profiles" / "r01_bench_default_line.json").read_text())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "solves/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    # value is the throughput of the timed steps
+    assert abs(d["value"] - d["config"]["instances_per_gpu"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
