@@ -36,7 +36,10 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
     // dispatch order: workgroups start in index order, so order[] decides which instance groups start first
     const int grp = P.order ? P.order[blockIdx.x] : (int)blockIdx.x;
     const int inst = grp * 4 + (lane >> 4);
-    const bool valid = (unsigned)inst < (unsigned)P.batch; // also rejects a negative entry of a caller-supplied order
+    // also rejects a negative or too large entry of a caller-supplied order: such a row stores nothing, and its live-in
+    // loads below address the last instance instead (inst_a), so a bad permutation cannot read out of bounds
+    const bool valid = (unsigned)inst < (unsigned)P.batch;
+    const int inst_a = valid ? inst : P.batch - 1;
     const bool is_x = r16 < NX;
     const bool is_u = (r16 >= NX) && (r16 < NX + NU);
     const float rho = P.rho;
@@ -65,10 +68,10 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
     float a[N], c[N], pd[N];
     // 32-bit element offset: lets the compiler address every array as SGPR base + one shared VGPR offset instead of
     // keeping a 64-bit address pair per array alive through the loop (the host checks batch*N*16 < 2^30)
-    const int rowbase = (inst * N) * 16 + r16;
+    const int rowbase = (inst_a * N) * 16 + r16;
     int wstart = 0;
     if (P.xref_mode == 1 && valid) wstart = P.xref_start[inst];
-    const int xref_off = inst * (int)P.xref_inst_stride + r16;
+    const int xref_off = inst_a * (int)P.xref_inst_stride + r16;
     const bool cold = P.cold_start != 0;
     const bool zdual = cold || (P.duals_zero != 0);
     float xrN = 0.f; // Xref_{N-1}(r)

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(WAVE, 3) void admm_rowloop_kernel(const RowParams P
     const int grp = P.order ? P.order[blockIdx.x] : (int)blockIdx.x; // dispatch order (tiny_batch_set_dispatch)
     const int inst = grp * 4 + (lane >> 4);
     const bool valid = (unsigned)inst < (unsigned)P.batch;
+    const int inst_a = valid ? inst : P.batch - 1; // load index of a row that stores nothing (padding, or a bad entry of a caller's order)
     const bool is_x = r16 < NX;
     const bool is_u = (r16 >= NX) && (r16 < NX + NU);
     const int N = P.N;
@@ -45,10 +46,10 @@ __global__ __launch_bounds__(WAVE, 3) void admm_rowloop_kernel(const RowParams P
     G.load(P.mats, r16);
 
     v32f a, c; // a[i] = g_i | y_i ;  c[i] = -(Xref_i .* Q) | d_i
-    const int rowbase = (inst * N) * 16 + r16;
+    const int rowbase = (inst_a * N) * 16 + r16;
     int wstart = 0;
     if (P.xref_mode == 1 && valid) wstart = P.xref_start[inst];
-    const int xref_off = inst * (int)P.xref_inst_stride + r16;
+    const int xref_off = inst_a * (int)P.xref_inst_stride + r16;
     const bool cold = P.cold_start != 0;
     const bool zdual = cold || (P.duals_zero != 0);
     float xrN = 0.f;

@@ -216,18 +216,31 @@ __device__ __forceinline__ void lqr_step(const RowGains<NX, NU> &G, bool is_x, b
     }
 }
 
-// plant step of the closed loop (examples/quadrotor_hovering.cpp:110): xn = Adyn*x + Bdyn*u with sv = [x ; u], always in
-// separately rounded sequential-order arithmetic — what the host-launched plant kernel computes — whatever the mode of
-// the solver, so that the on-chip closed loop and the step-by-step one continue from identical states
+// plant step of the closed loop (examples/quadrotor_hovering.cpp:110-111): xn = Adyn*x + Bdyn*u with sv = [x ; u], always in
+// the reference's own order whatever the arithmetic mode of the solver, so that the on-chip closed loop and the
+// step-by-step one (plant_step_kernel, tinympc_batch.hip) continue from identical states.  The order is Eigen's for
+// "x1 = work.Adyn * x0 + work.Bdyn * work.u.col(0)" (pinned against that expression compiled from the reference, tests/test_oracle.py:
+// test_plant_step_bit_exact_vs_compiled_reference): a product whose rows and depth are both >= 8 goes through the column-major GEMV kernel, whose row
+// accumulator starts at +0 (visible in the sign of a zero result); otherwise the lazy product's plain sequential sum.
 template <int NX, int NU>
 __device__ __forceinline__ float plant_step(const RowGains<NX, NU> &G, float sv)
 {
     using PL = RowPlans<NX, NU>;
     static_assert(PL::FWD_XA == PLAN_SEQ && PL::FWD_XB == PLAN_SEQ, "the plant kernel sums sequentially");
+    static_assert(!(NX >= 8 && NU >= 8), "Bdyn*u would take the GEMV kernel too; not needed for nx + nu <= 16");
     float t[NX], t2[NU];
     dpp_products<0, NX>(t, sv, G.M1);
     dpp_products<NX, NU>(t2, sv, G.M2);
-    return reduce<PLAN_SEQ>(t) + reduce<PLAN_SEQ>(t2);
+    float a = reduce<PLAN_SEQ>(t);
+    if constexpr (NX >= 8)
+    {
+        float z = 0.f;
+        asm("" : "+v"(z)); // keep the +0 start of the GEMV accumulator: (+0) + (-0) = +0
+        a = z + t[0];
+#pragma unroll
+        for (int k = 1; k < NX; k++) a = a + t[k];
+    }
+    return a + reduce<PLAN_SEQ>(t2);
 }
 
 // backward_pass_grad step (admm.cpp:19-20): from p = p_{i+1} (x rows) and lin = [q_i ; r_i] compute

@@ -137,6 +137,10 @@ __global__ void zero_kernel(float *__restrict__ dst, int layout, Geo g, int fam,
 
 // x0 <- Adyn*x0 + Bdyn*u.col(0)   (quadrotor_hovering.cpp:110-111), and x.col(0) <- x0 (:95).
 // One thread per instance; matrices column-major in global memory (tiny, cache resident).
+// Summation order = Eigen's for that expression (pinned bit for bit against that expression compiled from the reference, tests/test_oracle.py:
+// test_plant_step_bit_exact_vs_compiled_reference): dst = Adyn*x0, then dst += Bdyn*u0; a product whose rows and depth are both >= 8 takes the column-major
+// GEMV kernel (row accumulator starting at +0, products added in ascending column order), a smaller one the lazy product
+// (sequential from the first product for the nx % 4 == 0 classes this library serves).
 __global__ void plant_step_kernel(float *__restrict__ x0buf, float *__restrict__ xarr, const float *__restrict__ uarr,
                                   const float *__restrict__ A, const float *__restrict__ Bm, int *__restrict__ wstart,
                                   int window_advance, int batch, int layout, Geo g, int h16)
@@ -145,14 +149,15 @@ __global__ void plant_step_kernel(float *__restrict__ x0buf, float *__restrict__
     if (b >= batch) return;
     const int nx = g.nx, nu = g.nu;
     const float *x0 = x0buf + (long long)b * nx;
+    const bool gemv_a = nx >= 8, gemv_b = nx >= 8 && nu >= 8;
     float xn[64];
     for (int i = 0; i < nx; i++)
     {
-        // sequential sums starting from the first product: the order forward_pass uses for nx % 4 == 0 (admm.cpp:35), so
-        // that the on-chip closed loop of admm_rowlane.hip (which gets x_1 from its own forward step) continues bit-identically
         float acc = A[i] * x0[0];
+        if (gemv_a) acc = 0.f + acc;
         for (int k = 1; k < nx; k++) acc += A[k * nx + i] * x0[k];
         float acc2 = Bm[i] * get_elem(uarr, idx_of(layout, g, 1, b, 0, 0), h16);
+        if (gemv_b) acc2 = 0.f + acc2;
         for (int m = 1; m < nu; m++) acc2 += Bm[m * nx + i] * get_elem(uarr, idx_of(layout, g, 1, b, 0, m), h16);
         xn[i] = acc + acc2;
     }
@@ -289,6 +294,21 @@ namespace
 {
 
 Geo geo(const TinyBatch *tb) { return Geo{tb->nx, tb->nu, tb->N, tb->NXC, tb->NUC, tb->rw}; }
+
+// The hipGraph cached by tiny_batch_mpc_run_traj_async bakes in every kernel ARGUMENT of its launches (RowParams /
+// SolveParams are passed by value): rho, tolerances, bound flags, array pointers and strides, window advance.  Anything
+// that can change one of them drops the graph; the next mpc_run captures a fresh one.
+void invalidate_graph(TinyBatch *tb)
+{
+    if (tb->graph_exec)
+    {
+        (void)hipSetDevice(tb->device);
+        (void)hipStreamSynchronize(tb->stream); // a replay may still be in flight
+        (void)hipGraphExecDestroy(tb->graph_exec);
+        tb->graph_exec = nullptr;
+    }
+    tb->graph_sig.clear();
+}
 
 int set_device(TinyBatch *tb)
 {
@@ -452,6 +472,7 @@ int store_input(TinyBatch *tb, InputArr &in, const float *host, bool shared, int
     if (shared) in.host.assign(host, host + n);
     else in.host.clear();
     tb->derived_dirty[0] = tb->derived_dirty[1] = true;
+    invalidate_graph(tb); // shared <-> per-instance changes strides that a captured launch carries by value
     return 0;
 }
 
@@ -1024,6 +1045,7 @@ int tiny_batch_set_stream(TinyBatch *tb, void *hip_stream)
 {
     CHECK_TB(tb);
     tb->stream = (hipStream_t)hip_stream;
+    invalidate_graph(tb);
     return 0;
 }
 
@@ -1047,6 +1069,7 @@ int tiny_batch_set_cache(TinyBatch *tb, float rho, const float *Kinf, const floa
     tb->AmBKt.assign(AmBKt, AmBKt + (size_t)nx * nx);
     tb->have_cache = true;
     tb->gains_dirty = true;
+    invalidate_graph(tb); // rho is a kernel argument
     return 0;
 }
 
@@ -1059,6 +1082,7 @@ int tiny_batch_set_dynamics(TinyBatch *tb, const float *Adyn, const float *Bdyn,
     tb->Q.assign(Q, Q + nx);
     tb->have_dyn = true;
     tb->gains_dirty = true;
+    invalidate_graph(tb);
     return 0;
 }
 
@@ -1068,7 +1092,7 @@ int tiny_batch_set_optional_terms(TinyBatch *tb, int en_uref, int en_coeff_d2p)
     CHECK_TB(tb);
     tb->en_uref = en_uref != 0;
     tb->en_d2p = en_coeff_d2p != 0;
-    if (tb->graph_exec) { (void)hipGraphExecDestroy(tb->graph_exec); tb->graph_exec = nullptr; tb->graph_sig.clear(); }
+    invalidate_graph(tb);
     update_kname(tb);
     return 0;
 }
@@ -1079,6 +1103,7 @@ int tiny_batch_set_input_cost(TinyBatch *tb, const float *R)
     tb->Rcost.assign(R, R + tb->nu);
     tb->have_rcost = true;
     tb->gains_dirty = true;
+    invalidate_graph(tb);
     return 0;
 }
 
@@ -1087,6 +1112,7 @@ int tiny_batch_set_coeff_d2p(TinyBatch *tb, const float *coeff_d2p)
     CHECK_TB(tb); CHECK_PTR(coeff_d2p);
     tb->coeff_d2p.assign(coeff_d2p, coeff_d2p + (size_t)tb->nx * tb->nu);
     tb->gains_dirty = true;
+    invalidate_graph(tb);
     return 0;
 }
 
@@ -1103,7 +1129,7 @@ int tiny_batch_set_dispatch(TinyBatch *tb, int mode)
     CHECK_TB(tb);
     if (mode != 0 && mode != 1) return fail(TINY_BATCH_EINVAL, "tiny_batch_set_dispatch: mode must be 0 (index order) or 1 (longest first, predicted)");
     tb->dispatch_mode = mode;
-    if (tb->graph_exec) { (void)hipGraphExecDestroy(tb->graph_exec); tb->graph_exec = nullptr; tb->graph_sig.clear(); }
+    invalidate_graph(tb);
     return 0;
 }
 
@@ -1111,7 +1137,7 @@ int tiny_batch_set_dispatch_order_device(TinyBatch *tb, const int *d_order)
 {
     CHECK_TB(tb);
     tb->order_dev = d_order;
-    if (tb->graph_exec) { (void)hipGraphExecDestroy(tb->graph_exec); tb->graph_exec = nullptr; tb->graph_sig.clear(); }
+    invalidate_graph(tb);
     return 0;
 }
 
@@ -1126,6 +1152,7 @@ int tiny_batch_set_settings(TinyBatch *tb, float abs_pri_tol, float abs_dua_tol,
     tb->max_iter = max_iter; tb->check_termination = check_termination;
     tb->en_state_bound = en_state_bound; tb->en_input_bound = en_input_bound;
     tb->have_settings = true;
+    invalidate_graph(tb); // tolerances, max_iter, check_termination and the bound flags are kernel arguments
     return 0;
 }
 
@@ -1153,6 +1180,7 @@ int tiny_batch_set_xref(TinyBatch *tb, const float *xref, int shared)
     TRY(set_device(tb));
     TRY(store_input(tb, tb->in_xref, xref, shared != 0, tb->N, tb->nx));
     tb->xref_mode = 0;
+    invalidate_graph(tb);
     return 0;
 }
 
@@ -1191,6 +1219,7 @@ int tiny_batch_set_xref_window(TinyBatch *tb, const float *table, int rows, cons
     HIP_TRY(hipStreamSynchronize(tb->stream));
     tb->table_rows = rows;
     tb->xref_mode = 1;
+    invalidate_graph(tb);
     return 0;
 }
 
@@ -1380,6 +1409,7 @@ int tiny_batch_set_xref_device(TinyBatch *tb, const float *d_xref, int shared)
     in.host.clear(); // only the bounds are ever read on the host
     tb->derived_dirty[0] = tb->derived_dirty[1] = true;
     tb->xref_mode = 0;
+    invalidate_graph(tb);
     return 0;
 }
 
@@ -1394,6 +1424,7 @@ int tiny_batch_mpc_step_async(TinyBatch *tb, int window_advance)
 {
     CHECK_TB(tb);
     if (tb->nx > 64) return fail(TINY_BATCH_EUNSUPPORTED, "mpc_step supports nx <= 64");
+    if (window_advance < 0) return fail(TINY_BATCH_EINVAL, "tiny_batch_mpc_step_async: window_advance must be >= 0 (got %d): the window gather clamps at the last table row only", window_advance);
     // x.col(0) already holds x0 (set_x0 / previous plant step); reset duals, solve, then simulate forward.
     tb->duals_zero_pending = true;
     TRY(tiny_batch_solve_async(tb));
@@ -1410,6 +1441,7 @@ int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, 
 {
     CHECK_TB(tb);
     if (steps < 1) return fail(TINY_BATCH_EINVAL, "tiny_batch_mpc_run_async: steps must be >= 1");
+    if (window_advance < 0) return fail(TINY_BATCH_EINVAL, "tiny_batch_mpc_run_async: window_advance must be >= 0 (got %d): the window gather clamps at the last table row only", window_advance);
     if (tb->nx > 64) return fail(TINY_BATCH_EUNSUPPORTED, "mpc_run supports nx <= 64");
     if (tb->max_iter <= 0) return fail(TINY_BATCH_EINVAL, "tiny_batch_mpc_run_async needs max_iter > 0");
     TRY(set_device(tb));
@@ -1524,6 +1556,7 @@ int tiny_batch_set_row_kernel(TinyBatch *tb, int family)
         return fail(TINY_BATCH_EUNSUPPORTED, "row kernel %d has no instantiation for nx=%d nu=%d N=%d", family, tb->nx, tb->nu, tb->N);
     static const int kFam[5] = {-1, 0, 1, 2, 4};
     tb->row_family_forced = kFam[family];
+    invalidate_graph(tb);
     return 0;
 }
 
@@ -1538,6 +1571,7 @@ int tiny_batch_set_storage(TinyBatch *tb, int bits)
     if (want && tb->variant == VAR_STREAM) return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage cannot be combined with the streaming kernel");
     TRY(set_device(tb));
     HIP_TRY(hipStreamSynchronize(tb->stream));
+    invalidate_graph(tb);
     // the workspace restarts from zero in the new precision (like tiny_batch_create), inputs are re-derived
     free_layout(tb, LAYOUT_TILE);
     free_layout(tb, LAYOUT_ROW);
@@ -1562,6 +1596,7 @@ int tiny_batch_select_kernel(TinyBatch *tb, int variant)
     tb->variant = variant;
     int v = 0;
     if (int rc = resolve_variant(tb, &v)) { tb->variant = old; return rc; }
+    invalidate_graph(tb);
     TRY(set_device(tb));
     TRY(ensure_layout(tb, v == VAR_STREAM ? LAYOUT_TILE : LAYOUT_ROW));
     return 0;

@@ -143,8 +143,7 @@ class TinyBatchSolver:
         self.nx, self.nu, self.N, self.B = int(prob["nx"]), int(prob["nu"]), int(prob["N"]), int(batch)
         self._h = C.c_void_p()
         self._check(self.lib.tiny_batch_create(C.byref(self._h), self.nx, self.nu, self.N, self.B, int(device)))
-        k, p, qi, am = (_colmajor(prob[n]) for n in ("Kinf", "Pinf", "Quu_inv", "AmBKt"))
-        self._check(self.lib.tiny_batch_set_cache(self._h, float(prob["rho"]), _fp(k), _fp(p), _fp(qi), _fp(am)))
+        self.set_cache(prob)
         a, b, q = _colmajor(prob["Adyn"]), _colmajor(prob["Bdyn"]), _f32(np.asarray(prob["Q"]).ravel())
         self._check(self.lib.tiny_batch_set_dynamics(self._h, _fp(a), _fp(b), _fp(q)))
         s = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1, en_state_bound=1,
@@ -152,6 +151,11 @@ class TinyBatchSolver:
         if settings:
             s.update(settings)
         self.set_settings(**s)
+
+    def set_cache(self, prob: dict):
+        """TinyCache (types.hpp:26-34): rho, Kinf, Pinf, Quu_inv, AmBKt of `prob` (logical row/col numpy matrices)."""
+        k, p, qi, am = (_colmajor(prob[n]) for n in ("Kinf", "Pinf", "Quu_inv", "AmBKt"))
+        self._check(self.lib.tiny_batch_set_cache(self._h, float(prob["rho"]), _fp(k), _fp(p), _fp(qi), _fp(am)))
 
     # -- plumbing ---------------------------------------------------------------------------
     def _check(self, rc):
@@ -305,6 +309,23 @@ class TinyBatchSolver:
     def mpc_run_async(self, steps: int, window_advance: int = 0):
         """`steps` closed-loop MPC steps replayed from one captured hipGraph."""
         self._check(self.lib.tiny_batch_mpc_run_async(self._h, steps, window_advance))
+
+    def mpc_run_traj(self, steps: int, window_advance: int = 0) -> np.ndarray:
+        """tiny_batch_mpc_run_traj_async + copy-out: runs `steps` closed-loop MPC steps and returns u.col(0) of every step,
+        shape (steps, B, nu).  The trajectory buffer lives in device memory for the duration of the call."""
+        hip = C.CDLL("libamdhip64.so")
+        out = np.zeros((steps, self.B, self.nu), np.float32)
+        d = C.c_void_p()
+        if hip.hipMalloc(C.byref(d), C.c_size_t(out.nbytes)) != 0:
+            raise TinyBatchError("hipMalloc of the trajectory buffer failed")
+        try:
+            self._check(self.lib.tiny_batch_mpc_run_traj_async(self._h, steps, window_advance, d))
+            self.synchronize()
+            if hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), d, C.c_size_t(out.nbytes), 2) != 0:
+                raise TinyBatchError("hipMemcpy of the trajectory buffer failed")
+        finally:
+            hip.hipFree(d)
+        return out
 
     def get_x0(self):
         out = np.empty((self.B, self.nx), np.float32)

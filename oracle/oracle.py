@@ -238,6 +238,21 @@ class Oracle(_Solver):
                                       w.dual_residual_input)
         return out
 
+    def plant_step(self, x0, u0):
+        """x1 = Adyn*x0 + Bdyn*u0 per instance, in the order of the reference's examples (quadrotor_hovering.cpp:110-111).
+        Always the scalar type's own arithmetic (the simulated plant is not a work array: no fp16 rounding)."""
+        dt, ct = self.T.np, self.T.ct
+        x0 = np.ascontiguousarray(x0, dt).reshape(-1, self.nx)
+        u0 = np.ascontiguousarray(u0, dt).reshape(-1, self.nu)
+        x1 = np.empty_like(x0)
+        suf = "f32" if self.T.h16 else self.T.suf
+        f = getattr(self.lib, f"oracle_plant_step_batch_{suf}")
+        f.restype = None
+        f.argtypes = [C.POINTER(self.PS), C.c_int, C.POINTER(ct), C.POINTER(ct), C.POINTER(ct)]  # the _h16 struct has the f32 layout
+        ps = self._pstruct()
+        f(C.byref(ps), x0.shape[0], _ptr(x0, ct), _ptr(u0, ct), _ptr(x1, ct))
+        return x1
+
     def solve(self, st, x_min, x_max, u_min, u_max, Xref, nthreads=1, ftz=False):
         """One tiny_solve() per instance, in place on `st`.  Returns #instances that hit max_iter."""
         B, ins, (sx, su, sr) = self._prep(st, x_min, x_max, u_min, u_max, Xref)
@@ -284,6 +299,19 @@ class Reference(_Solver):
         self.lib.ref_solve_batch.argtypes = ([C.c_int] + [P] * 17 + [C.c_longlong] * 3 +
                                              [P, C.POINTER(C.c_int), C.POINTER(C.c_int)])
         self.lib.ref_solve_batch.restype = C.c_int
+
+    def plant_step(self, x0, u0):
+        """The examples' own Eigen expression x1 = work.Adyn*x0 + work.Bdyn*work.u.col(0) (ref_shim.cpp: ref_plant_step)."""
+        dt, ct = self.T.np, self.T.ct
+        x0 = np.ascontiguousarray(x0, dt).reshape(-1, self.nx)
+        u0 = np.ascontiguousarray(u0, dt).reshape(-1, self.nu)
+        x1 = np.empty_like(x0)
+        self.lib.ref_set_problem(self.rho, *[_ptr(self._m[k], ct) for k in
+                                 ("Kinf", "Pinf", "Quu_inv", "AmBKt", "Adyn", "Bdyn", "Q")])
+        self.lib.ref_plant_step_batch.restype = None
+        self.lib.ref_plant_step_batch.argtypes = [C.c_int] + [C.POINTER(ct)] * 3
+        self.lib.ref_plant_step_batch(x0.shape[0], _ptr(x0, ct), _ptr(u0, ct), _ptr(x1, ct))
+        return x1
 
     def solve(self, st, x_min, x_max, u_min, u_max, Xref, nthreads=1, ftz=False):
         assert nthreads == 1, "the reference is single-threaded (one global solver, tiny_wrapper.cpp)"

@@ -128,4 +128,27 @@ extern "C"
         }
         return unsolved;
     }
+
+    /*
+     * The plant step of the reference's closed-loop examples, examples/quadrotor_hovering.cpp:110-111 and
+     * examples/quadrotor_tracking.cpp:116-117:
+     *     x1 = work.Adyn * x0 + work.Bdyn * work.u.col(0);   x0 = x1;
+     * evaluated by Eigen over the same types (tiny_VectorNx, the workspace's Adyn/Bdyn/u members), so that the order of
+     * its sums is the compiled reference's, not a restatement.  Uses the problem loaded by ref_set_problem().
+     */
+    void ref_plant_step(const tinytype *x0_in, const tinytype *u0_in, tinytype *x1_out)
+    {
+        TinyWorkspace &work = g_work;
+        tiny_VectorNx x0, x1;
+        std::memcpy(x0.data(), x0_in, sizeof(tinytype) * NSTATES);
+        std::memcpy(work.u.data(), u0_in, sizeof(tinytype) * NINPUTS); /* work.u.col(0) */
+        x1 = work.Adyn * x0 + work.Bdyn * work.u.col(0);
+        x0 = x1;
+        std::memcpy(x1_out, x0.data(), sizeof(tinytype) * NSTATES);
+    }
+
+    void ref_plant_step_batch(int batch, const tinytype *x0, const tinytype *u0, tinytype *x1)
+    {
+        for (int b = 0; b < batch; b++) ref_plant_step(x0 + (long long)b * NSTATES, u0 + (long long)b * NINPUTS, x1 + (long long)b * NSTATES);
+    }
 }

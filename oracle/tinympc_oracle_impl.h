@@ -346,6 +346,42 @@ int SUF(oracle_tiny_solve)(const SUF(OracleProblem) * P, SUF(OracleWork) * W)
 }
 
 /*
+ * Plant step of the reference's closed-loop examples (examples/quadrotor_hovering.cpp:110-111,
+ * examples/quadrotor_tracking.cpp:116-117):   x1 = work.Adyn * x0 + work.Bdyn * work.u.col(0);
+ * Eigen evaluates "dst = prod1 + prod2" as  dst = prod1;  dst += prod2  (ProductEvaluators.h,
+ * assignment_from_xpr_op_product), and each product by its own product_type_selector (GeneralProduct.h): rows >= 8 and
+ * depth >= 8 (EIGEN_CACHEFRIENDLY_PRODUCT_THRESHOLD) -> GemvProduct = the column-major kernel of
+ * products/GeneralMatrixVector.h:108-260: per result row an accumulator that starts at ZERO, the products added to it in
+ * ascending column order (pmadd without FMA on SSE2 = multiply, then add), finally res = acc*alpha + res with alpha = 1 and
+ * res = 0 (dst.setZero() of evalTo) or the value already in dst (addTo).  Otherwise the coefficient-based lazy product
+ * of row_dot() above.  Pinned bit for bit against oracle/ref_shim.cpp: ref_plant_step (tests/test_oracle.py).
+ */
+static REAL SUF(dot_gemv_cm)(const REAL *M, int rows, int cols, int i, const REAL *xin, REAL res)
+{
+    REAL c = 0;
+    for (int j = 0; j < cols; j++) c = M[(size_t)j * rows + i] * xin[j] + c;
+    return c * (REAL)1 + res;
+}
+
+void SUF(oracle_plant_step)(const SUF(OracleProblem) * P, const REAL *x0, const REAL *u0, REAL *x1)
+{
+    const int nx = P->nx, nu = P->nu;
+    REAL out[ORACLE_MAX_DIM];
+    for (int i = 0; i < nx; i++)
+    {
+        const REAL a = (nx >= 8) ? SUF(dot_gemv_cm)(P->Adyn, nx, nx, i, x0, (REAL)0) : SUF(row_dot)(P->Adyn, nx, nx, i, x0);
+        out[i] = (nx >= 8 && nu >= 8) ? SUF(dot_gemv_cm)(P->Bdyn, nx, nu, i, u0, a) : a + SUF(row_dot)(P->Bdyn, nx, nu, i, u0);
+    }
+    for (int i = 0; i < nx; i++) x1[i] = out[i];
+}
+
+void SUF(oracle_plant_step_batch)(const SUF(OracleProblem) * P, int batch, const REAL *x0, const REAL *u0, REAL *x1)
+{
+    for (int b = 0; b < batch; b++)
+        SUF(oracle_plant_step)(P, x0 + (size_t)b * P->nx, u0 + (size_t)b * P->nu, x1 + (size_t)b * P->nx);
+}
+
+/*
  * Batched convenience driver (the batch is our addition; the reference has none).
  * Host-visible layout = array of reference-layout instances: (B, N, nx) / (B, N-1, nu),
  * instance-major.  Bounds / Xref may be per-instance or shared (stride 0).

@@ -16,6 +16,9 @@ Scenarios:
   random_f32_32_16_50  seeded nx=32,nu=16 system, gains from tiny_codegen(), 2 solves x 4 instances
   dims_f32_8_3_7       odd sizes (nx, nu not multiples of 4), random stable system
   riccati_*            reference tiny_codegen() cache for cartpole and the random system
+  closed_loop_traces   whole closed loops of the compiled reference (tiny_solve + the examples' Eigen plant step) over
+                       batches of 64 (20) instances: u.col(0), iter, status of EVERY step and the final x0 — hovering 70
+                       steps, tracking 110 steps with sliding per-instance windows, cartpole 100 steps, (8,3,7) 25 steps
 """
 import ctypes as C
 import json
@@ -86,7 +89,6 @@ def closed_loop(prob, dt, N, x0, xref_fn, steps, keep, settings=None, batch_firs
     xmn, xmx, umn, umx = pr.bounds_arrays(prob, dt)
     B = x0.shape[0]
     st = O.new_state(B, nx, nu, N, dt)
-    A, Bm = prob["Adyn"].astype(dt), prob["Bdyn"].astype(dt)
     x0 = x0.astype(dt).copy()
     rec, trace = [], []
     for k in range(steps):
@@ -99,7 +101,9 @@ def closed_loop(prob, dt, N, x0, xref_fn, steps, keep, settings=None, batch_firs
         trace.append((int(rc), st["iter"].copy(), st["status"].copy(), st["u"][:, 0].copy()))
         if k in keep:
             rec.append(dict(k=k, pre=pre, post=O.copy_state(st), xref=xref.copy(), rc=int(rc)))
-        x0 = (x0 @ A.T + st["u"][:, 0] @ Bm.T).astype(dt)
+        # the examples' own Eigen expression x1 = work.Adyn*x0 + work.Bdyn*work.u.col(0) (quadrotor_hovering.cpp:110-111),
+        # compiled from the reference's types (oracle/ref_shim.cpp: ref_plant_step) — not a numpy matmul
+        x0 = ref.plant_step(x0, st["u"][:, 0])
     return rec, trace
 
 
@@ -201,5 +205,57 @@ def main():
     save("dims_f32_8_3_7", od, np.float32, S, recs)
 
 
+def closed_loop_traces():
+    """Whole closed loops through the compiled reference; data only (inputs + per-step outputs)."""
+    S = dict(O.DEFAULT_SETTINGS)
+    d, meta = {}, {}
+
+    def run(name, prob, N, x0, xref_fn, steps, settings, extra_meta):
+        _, trace = closed_loop(prob, np.float32, N, x0, xref_fn, steps, set(), settings=settings)
+        ref = O.Reference(prob, np.float32, settings)
+        # final state x0 after the last plant step: replay the last step's plant from the recorded u0
+        d[f"{name}_x0"] = x0.astype(np.float32)
+        d[f"{name}_u0"] = np.stack([t[3] for t in trace])           # (steps, B, nu)
+        d[f"{name}_iter"] = np.stack([t[1] for t in trace])         # (steps, B)
+        d[f"{name}_status"] = np.stack([t[2] for t in trace])
+        xs = x0.astype(np.float32).copy()
+        for t in trace:
+            xs = ref.plant_step(xs, t[3])
+        d[f"{name}_x_final"] = xs
+        meta[name] = dict(steps=steps, B=int(x0.shape[0]), N=N, settings=settings, **extra_meta)
+        print(f"  {name}: {steps} steps x {x0.shape[0]} instances, mean iterations {d[name + '_iter'].mean():.2f}, "
+              f"converged on the last step {np.mean(d[name + '_status'][-1] == 1):.2f}")
+
+    prob = pr.quadrotor(20, 30)
+    hov = np.tile(pr.HOVER_XREF, (30, 1))
+    x0h, _ = pr.hover_batch(64, 30, seed=21)
+    x0h[0] = pr.HOVER_X0                                   # instance 0 = the example itself
+    run("hover", prob, 30, x0h, lambda k: hov, 70, S, dict(problem="quadrotor_20hz", xref="hover"))
+    table = pr.y_axis_line().astype(np.float32)
+    start = (np.arange(64) * 3 % 100).astype(np.int32)     # per-instance window phases; instance 0 = the example (start 0)
+    rng = np.random.default_rng(22)
+    x0t = (table[start] + rng.uniform(-0.05, 0.05, size=(64, 12))).astype(np.float32)
+    x0t[0] = table[0]
+    d["track_start"] = start
+    run("track", prob, 30, x0t, lambda k: pr.expand_windows(table, start + k, 30), 110, S,
+        dict(problem="quadrotor_20hz", xref="window of y_axis_line, start_b + k", window_advance=1))
+    z = np.load(OUT / "riccati_cartpole.npz")
+    cp = dict(pr.cartpole(10, riccati=O.riccati), Kinf=z["Kinf"], Pinf=z["Pinf"], Quu_inv=z["Quu_inv"], AmBKt=z["AmBKt"])
+    S150 = dict(S, max_iter=150)
+    x0c = np.array([[0.0, 0, 0.1, 0]]) + np.random.default_rng(23).uniform(-0.05, 0.05, size=(64, 4))
+    x0c[0] = [0.0, 0, 0.1, 0]
+    zr = np.zeros((10, 4))
+    run("cartpole", cp, 10, x0c, lambda k: zr, 100, S150, dict(problem="cartpole (reference tiny_codegen cache, riccati_cartpole.npz)", xref="zero"))
+    od = pr.random_system(8, 3, 7, seed=99, riccati=O.riccati)
+    x0o = np.random.default_rng(24).uniform(-1, 1, size=(20, 8))
+    xro = np.random.default_rng(4).uniform(-0.2, 0.2, size=(7, 8))
+    run("dims837", od, 7, x0o, lambda k: xro, 25, S, dict(problem="random_system(8,3,7,seed=99)", xref="fixed random"))
+    d["dims837_xref"] = xro
+    d["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(OUT / "closed_loop_traces.npz", **d)
+    print(f"wrote closed_loop_traces.npz ({(OUT / 'closed_loop_traces.npz').stat().st_size / 1024:.1f} KiB)")
+
+
 if __name__ == "__main__":
     main()
+    closed_loop_traces()

@@ -45,3 +45,30 @@ def scale_of(name, prob):
     if name in ("x", "v", "vnew"):
         return 1.0
     return 1.0
+
+
+def closed_loop_case(pr, O, z, name):
+    """(prob, x0, xref_fn(k), steps, settings, window table/start or None) of one scenario of closed_loop_traces.npz"""
+    meta = json.loads(bytes(z["meta"]).decode())[name]
+    if name in ("hover", "track"):
+        prob = pr.quadrotor(20, 30)
+    elif name == "cartpole":
+        rc = np.load(GOLDEN / "riccati_cartpole.npz")
+        prob = dict(pr.cartpole(10, riccati=O.riccati), Kinf=rc["Kinf"], Pinf=rc["Pinf"], Quu_inv=rc["Quu_inv"], AmBKt=rc["AmBKt"])
+    else:
+        prob = pr.random_system(8, 3, 7, seed=99, riccati=O.riccati)
+    N = meta["N"]
+    table = start = None
+    if name == "hover":
+        xr = np.tile(pr.HOVER_XREF, (N, 1)).astype(np.float32)
+        fn = lambda k: xr
+    elif name == "track":
+        table, start = pr.y_axis_line().astype(np.float32), z["track_start"]
+        fn = lambda k: pr.expand_windows(table, start + k, N)
+    elif name == "cartpole":
+        xr = np.zeros((N, 4), np.float32)
+        fn = lambda k: xr
+    else:
+        xr = z["dims837_xref"].astype(np.float32)
+        fn = lambda k: xr
+    return prob, z[f"{name}_x0"], fn, meta["steps"], meta["settings"], table, start

@@ -3,7 +3,7 @@ and, where oracle/_ref is present, bit-for-bit against the compiled reference it
 import numpy as np
 import pytest
 
-from helpers import STATE_ORDER, bounds_of, load_fixture
+from helpers import GOLDEN as GOLDEN_DIR, STATE_ORDER, bounds_of, closed_loop_case, load_fixture
 
 FIXTURES = ["quad_hover_f32_N30", "quad_hover_f64_N10", "quad_track_f32_N30", "quad_batch_f32_N30",
             "quad_trackbatch_f32_N30", "cartpole_f32_N10", "random_f32_32_16_50", "dims_f32_8_3_7"]
@@ -266,3 +266,54 @@ int main() {{
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "iters 476" in r.stdout, r.stdout   # "Kinf converged after 476 iterations" 
+
+
+@pytest.mark.parametrize("dt,nx,nu,N", CFGS)
+def test_plant_step_bit_exact_vs_compiled_reference(oracle_mod, tinympc, dt, nx, nu, N):
+    """x1 = work.Adyn*x0 + work.Bdyn*work.u.col(0) (examples/quadrotor_hovering.cpp:110-111): the oracle's restatement of
+    Eigen's evaluation order against that very expression compiled from the reference's types (ref_shim.cpp:
+    ref_plant_step), zeros and negative zeros included."""
+    O = oracle_mod
+    if not O.have_ref(dt, nx, nu, N):
+        pytest.skip("oracle/_ref not built here (needs /root/reference)")
+    pr = tinympc.problems
+    if (nx, nu) == (12, 4):
+        prob = pr.quadrotor(20, N)
+    elif (nx, nu) == (4, 1):
+        prob = pr.cartpole(N, riccati=O.riccati)
+    else:
+        prob = pr.random_system(nx, nu, N, seed=nx * 100 + nu, riccati=O.riccati)
+    rng = np.random.default_rng(nx * 7 + nu)
+    B = 3000
+    x0 = (rng.standard_normal((B, nx)) * 0.5).astype(dt)
+    u0 = (rng.standard_normal((B, nu)) * 0.3).astype(dt)
+    for a in (x0, u0):
+        a[rng.random(a.shape) < 0.15] = 0.0
+        a[rng.random(a.shape) < 0.15] = -0.0
+    x0[:10] = 0.0; u0[:10] = -0.0; x0[10:20] = -0.0; u0[10:20] = 0.0
+    r = O.Reference(prob, dt).plant_step(x0, u0)
+    o = O.Oracle(prob, dt).plant_step(x0, u0)
+    assert np.array_equal(r, o) and np.array_equal(np.signbit(r), np.signbit(o))
+
+
+@pytest.mark.parametrize("name", ["hover", "track", "cartpole", "dims837"])
+def test_oracle_closed_loop_reproduces_reference_traces(oracle_mod, tinympc, name):
+    """Whole closed loops (tiny_solve + the examples' plant step, duals reset every step, warm start, sliding windows) of
+    the COMPILED REFERENCE, recorded in tests/golden/closed_loop_traces.npz, reproduced by the oracle bit for bit:
+    u.col(0), iter and status of every step and the final state."""
+    O, pr = oracle_mod, tinympc.problems
+    z = np.load(GOLDEN_DIR / "closed_loop_traces.npz")
+    prob, x0, xref_fn, steps, settings, _, _ = closed_loop_case(pr, O, z, name)
+    orc = O.Oracle(prob, np.float32, settings)
+    B = x0.shape[0]
+    bnds = pr.bounds_arrays(prob)
+    st = O.new_state(B, prob["nx"], prob["nu"], prob["N"])
+    x = x0.copy()
+    for k in range(steps):
+        st["x"][:, 0] = x
+        st["y"][:] = 0; st["g"][:] = 0
+        orc.solve(st, *bnds, xref_fn(k), nthreads=4)
+        assert np.array_equal(st["u"][:, 0], z[f"{name}_u0"][k]), (name, k)
+        assert np.array_equal(st["iter"], z[f"{name}_iter"][k]) and np.array_equal(st["status"], z[f"{name}_status"][k]), (name, k)
+        x = orc.plant_step(x, st["u"][:, 0])
+    assert np.array_equal(x, z[f"{name}_x_final"])

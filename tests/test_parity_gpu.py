@@ -1445,3 +1445,119 @@ def test_predicted_longest_first_dispatch(tinympc, oracle_mod, exact, family):
             st = O.new_state(idx.size, 12, 4, 30); st["x"][:, 0] = x0[idx]
             O.Oracle(prob, np.float32, settings).solve(st, *pr.bounds_arrays(prob), pr.expand_windows(table, start[idx], 30), nthreads=8)
             assert_bitwise({k: res[1][0][k][idx] for k in STATE_ORDER + SCALARS}, st, "dispatch 1 vs oracle")
+
+
+CLOSED_LOOP_CASES = [("hover", "row_exact"), ("hover", "loop_exact"), ("hover", "rowstream_exact"),
+                     ("track", "row_exact"), ("track", "loop_exact"), ("track", "rowstream_exact"),
+                     ("cartpole", "row_exact"), ("cartpole", "lane_exact"), ("cartpole", "loop_exact"),
+                     ("dims837", "row_exact"), ("dims837", "loop_exact")]
+
+
+@pytest.mark.parametrize("name,variant_name", CLOSED_LOOP_CASES)
+def test_device_closed_loop_equals_reference_trace(tinympc, oracle_mod, name, variant_name):
+    """the device closed loop against the COMPILED REFERENCE's closed loop (tiny_solve + the examples' own
+    Eigen plant step x1 = work.Adyn*x0 + work.Bdyn*work.u.col(0), quadrotor_hovering.cpp:90-114, quadrotor_tracking.cpp:93-118),
+    recorded in tests/golden/closed_loop_traces.npz: 70 hovering steps, 110 tracking steps with sliding per-instance
+    windows, 100 cartpole steps, 25 steps of the (8,3,7) class, 64 (20) instances each.  Exact arithmetic: u.col(0) of EVERY
+    step, the iteration counts and statuses and the final plant state must be equal bit for bit — through
+    tiny_batch_mpc_run_traj_async (on-chip loop for the unrolled row kernel and the quad kernel, hipGraph replay for the
+    others) and through the step-by-step tiny_batch_mpc_step_async loop."""
+    from helpers import GOLDEN, closed_loop_case
+    O, pr = oracle_mod, tinympc.problems
+    z = np.load(GOLDEN / "closed_loop_traces.npz")
+    prob, x0, xref_fn, steps, settings, table, start = closed_loop_case(pr, O, z, name)
+    B = x0.shape[0]
+    adv = 1 if table is not None else 0
+
+    def fresh():
+        s = make_solver(tinympc, prob, B, settings, None, variant_name, pr.bounds_arrays(prob))
+        if table is not None:
+            s.set_xref_window(table, start)
+        else:
+            s.set_xref(xref_fn(0))
+        s.set_x0(x0)
+        return s
+    a = fresh()
+    kn = a.kernel_name()
+    if name == "cartpole" and variant_name == "row_exact":
+        assert kn.startswith("quadlane"), kn
+    # (1) all steps in one call, split in two runs so that the continuation across calls is covered too
+    k1 = steps // 3
+    traj = np.concatenate([a.mpc_run_traj(k1, adv), a.mpc_run_traj(steps - k1, adv)])
+    assert np.array_equal(traj, z[f"{name}_u0"]), f"{kn}: u.col(0) differs from the reference's closed loop at step " \
+        f"{int(np.argmax(np.any(traj != z[name + '_u0'], axis=(1, 2))))}"
+    assert np.array_equal(np.signbit(traj), np.signbit(z[f"{name}_u0"]))
+    it, stt, _ = a.get_status()
+    assert np.array_equal(it, z[f"{name}_iter"][-1]) and np.array_equal(stt, z[f"{name}_status"][-1])
+    xf = a.get_x0()
+    assert np.array_equal(xf, z[f"{name}_x_final"]) and np.array_equal(np.signbit(xf), np.signbit(z[f"{name}_x_final"])), kn
+    a.close()
+    # (2) step by step: iteration counts and statuses of every step
+    b = fresh()
+    for k in range(steps):
+        b.mpc_step_async(adv)
+        it, stt, _ = b.get_status()
+        assert np.array_equal(it, z[f"{name}_iter"][k]) and np.array_equal(stt, z[f"{name}_status"][k]), (kn, k)
+        assert np.array_equal(b.get_u()[:, 0], z[f"{name}_u0"][k]), (kn, k)
+    assert np.array_equal(b.get_x0(), z[f"{name}_x_final"])
+    b.close()
+
+
+@pytest.mark.parametrize("variant_name", ["loop_exact", "rowstream_exact", "stream"])
+def test_mpc_run_graph_is_rebuilt_when_its_arguments_change(tinympc, variant_name):
+    """The hipGraph that tiny_batch_mpc_run_async replays carries rho, the bound flags and the reference strides as kernel
+    ARGUMENTS: after set_cache (another rho), set_settings (bound flags) or a switch between a shared and a per-instance
+    reference a replay of the old graph would silently use stale values.  Each change must give what a fresh handle,
+    configured the same way and advanced step by step, gives."""
+    pr = tinympc.problems
+    prob = pr.quadrotor(20, 30)
+    B, K = 40, 4
+    x0, table, start = pr.tracking_batch(B, 30, seed=13)
+    bnds = pr.bounds_arrays(prob)
+    xr_shared = np.tile(pr.HOVER_XREF, (30, 1)).astype(np.float32)
+    xr_inst = pr.expand_windows(table, start, 30)
+    # a cache for another rho: same gains, the solver only reads rho from it in the iteration (a self-consistent cache is
+    # not needed for this test: both handles use the same numbers)
+    prob2 = dict(prob, rho=prob["rho"] * 0.5)
+
+    def configure(s, stage):
+        s.set_xref(xr_shared if stage < 2 else xr_inst)          # stage 2: shared -> per-instance reference (strides)
+        if stage >= 1:
+            s.set_cache(prob2)                                    # stage 1: rho
+        if stage >= 3:
+            s.set_settings(**dict(s.settings, en_state_bound=0))  # stage 3: bound flag
+    a = make_solver(tinympc, prob, B, None, xr_shared, variant_name, bnds)
+    a.set_x0(x0)
+    for stage in range(4):
+        configure(a, stage)
+        a.mpc_run_async(K, 0)
+        b = make_solver(tinympc, prob, B, None, xr_shared, variant_name, bnds)
+        configure(b, stage)
+        b.set_x0(x0)
+        # bring b to a's state before this stage's run, then advance it step by step
+        if stage:
+            b.set_state(prev_state); b.set_x0(prev_x0)
+        for _ in range(K):
+            b.mpc_step_async(0)
+        sa, sb = a.get_state(), b.get_state()
+        for k in STATE_ORDER + SCALARS:
+            assert np.array_equal(sa[k], sb[k]), f"{a.kernel_name()} stage {stage}: {k}"
+        assert np.array_equal(a.get_x0(), b.get_x0())
+        prev_state, prev_x0 = sa, a.get_x0()
+        b.close()
+    a.close()
+
+
+def test_negative_window_advance_is_refused(tinympc):
+    pr = tinympc.problems
+    prob = pr.quadrotor(20, 30)
+    x0, table, start = pr.tracking_batch(8, 30, seed=1)
+    s = tinympc.TinyBatchSolver(prob, 8)
+    s.set_bounds(*pr.bounds_arrays(prob)); s.set_xref_window(table, start); s.set_x0(x0)
+    with pytest.raises(tinympc.TinyBatchError):
+        s.mpc_step_async(-1)
+    with pytest.raises(tinympc.TinyBatchError):
+        s.mpc_run_async(3, -2)
+    s.mpc_step_async(1)   # the handle stays usable
+    assert s.get_status()[0].min() >= 1
+    s.close()
