@@ -141,6 +141,16 @@ def tracking_batch(B: int, N: int = 30, seed: int = 20241024, spread: float = 0.
     return x0.astype(np.float32), table.astype(np.float32), start
 
 
+def random_batch(B: int, nx: int = 32, N: int = 50, seed: int = 20241024):
+    """BASELINE.json config 4: x0_b ~ U(-1, 1)^nx, reference = the origin, shared by the batch.
+
+    Returns (x0 (B,nx) float32, Xref (N,nx) float32).  Row b is the same whatever B is (the generator fills row-major).
+    """
+    rng = np.random.default_rng(seed)
+    x0 = rng.uniform(-1.0, 1.0, size=(B, nx))
+    return x0.astype(np.float32), np.zeros((N, nx), np.float32)
+
+
 def expand_windows(table: np.ndarray, start: np.ndarray, N: int) -> np.ndarray:
     """Materialise per-instance references (B, N, nx) from a trajectory table and window starts."""
     idx = start[:, None].astype(np.int64) + np.arange(N)[None, :]

@@ -35,52 +35,78 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-NX, NU, N = 12, 4, 30
-# ALGORITHMIC cost model of SURVEY.md §8(d) (stated in DESIGN.md):
-#   bytes per solve = every live-in array read once + every live-out array written once, bounds shared
-B_SOLVE = (NX + 3 * NU * (N - 1) + 3 * NX * N + 6 * NX * N + 6 * NU * (N - 1)) * 4 + 24           # 17 208 B
-#   flops per ADMM iteration; the converged iteration omits the backward sweep
-F_FWD = (N - 1) * (2 * NX * NX + 4 * NX * NU + NX + NU) + 2 * NX * NX + 13 * (NX * N + NU * (N - 1))
-F_BWD = (N - 1) * (2 * NX * NX + 4 * NX * NU + 2 * NU * NU + 2 * NX + NU)
+# Workloads.  "tracking" is the one BASELINE.json's metric is quoted on (configs[2]) and the default; "random32" is
+# configs[3] (codegen_random scaled to nx=32, nu=16, N=50: 16 384 instances in all, block-sharded over the ranks).
+CONFIGS = {
+    "tracking": dict(nx=12, nu=4, N=30, per_gpu=65536, scaling="weak",
+                     metric="MPC solves/sec (batched quadrotor nx=12,nu=4,N=30)"),
+    "random32": dict(nx=32, nu=16, N=50, total=16384, scaling="strong",
+                     metric="MPC solves/sec (batched codegen_random nx=32,nu=16,N=50, 16384 instances over the GPUs)"),
+}
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
 
 
-def flops_of(iters: np.ndarray, status: np.ndarray) -> float:
-    it = iters.astype(np.float64)
-    return float(np.sum(it * F_FWD + (it - (status == 1)) * F_BWD))
+class Cost:
+    """ALGORITHMIC cost model of SURVEY.md §8(d) (stated in DESIGN.md §5.1/§6) for one problem class."""
+
+    def __init__(self, nx, nu, N):
+        # bytes per solve = every live-in array read once + every live-out array written once, bounds shared
+        self.b_solve = (nx + 3 * nu * (N - 1) + 3 * nx * N + 6 * nx * N + 6 * nu * (N - 1)) * 4 + 24   # Q: 17 208 B, R: 85 976 B
+        # flops per ADMM iteration; the converged iteration omits the backward sweep
+        self.f_fwd = (N - 1) * (2 * nx * nx + 4 * nx * nu + nx + nu) + 2 * nx * nx + 13 * (nx * N + nu * (N - 1))
+        self.f_bwd = (N - 1) * (2 * nx * nx + 4 * nx * nu + 2 * nu * nu + 2 * nx + nu)
+
+    def flops_of(self, iters: np.ndarray, status: np.ndarray) -> float:
+        it = iters.astype(np.float64)
+        return float(np.sum(it * self.f_fwd + (it - (status == 1)) * self.f_bwd))
 
 
-def cpu_baseline(prob, pr, seconds_target=12.0):
+def kernel_source_sha() -> str:
+    """sha256 over the kernel sources: binds a committed PMC figure (profiles/hbm_traffic.json) to the code it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "accelerated-tinympc_amd" / "csrc").glob("*")):
+        if f.suffix in (".hip", ".h", ".cpp"):
+            h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(prob, make_batch, seconds_target=12.0):
     """Time the reference's own CPU path (oracle/_ref, compiled Eigen code, 1 thread — it is single threaded) or,
-    if that prebuilt library is absent, our C port (oracle/), on a bounded sample of the same workload."""
+    if that prebuilt library is absent, our C port (oracle/), on a bounded sample of the same workload.
+    `make_batch(nb)` -> (x0, Xref) of the FIRST nb instances of the benchmarked batch.  Returns the JSON object and the
+    reference's live-out of the first pass (the parity sample of the bench line)."""
+    import accelerated_tinympc_amd as T
     from oracle import oracle as O
+    pr = T.problems
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
     xmn, xmx, umn, umx = pr.bounds_arrays(prob)
-    kind = "reference" if O.have_ref(np.float32, NX, NU, N) else "port"
+    kind = "reference" if O.have_ref(np.float32, nx, nu, N) else "port"
     solver = (O.Reference if kind == "reference" else O.Oracle)(prob, np.float32)
 
     def run(nb, cls_solver, nthreads=1):
-        x0, table, start = pr.tracking_batch(nb, N)
-        st = O.new_state(nb, NX, NU, N)
+        x0, xr = make_batch(nb)
+        st = O.new_state(nb, nx, nu, N)
         st["x"][:, 0] = x0
-        xr = pr.expand_windows(table, start, N)
         t0 = time.perf_counter()
         cls_solver.solve(st, xmn, xmx, umn, umx, xr, nthreads=nthreads)
         return time.perf_counter() - t0, st
 
     def timed(solver_, nthreads, budget_s, chunk):
         """repeat cold-start passes over `chunk` instances until ~budget_s of wall time has been spent"""
-        n, t, its = 0, 0.0, []
+        n, t, its, first = 0, 0.0, [], None
         while t < budget_s:
             dt, st = run(chunk, solver_, nthreads)
+            first = st if first is None else first
             n += chunk; t += dt; its.append(st["iter"].mean())
-        return n, t, float(np.mean(its))
+        return n, t, float(np.mean(its)), first
 
-    t_probe, _ = run(256, solver)
-    chunk = int(min(32768, max(256, 256 * 2.0 / max(t_probe, 1e-6))))
-    nb, t, mi = timed(solver, 1, seconds_target, chunk)
+    t_probe, _ = run(64, solver)
+    chunk = int(min(32768, max(64, 64 * 2.0 / max(t_probe, 1e-6))))
+    nb, t, mi, first = timed(solver, 1, seconds_target, chunk)
     out = dict(value=nb / t, unit="solves/s", cores=1, kind=kind,
-               sample=f"{nb} cold-start tiny_solve calls on the same tracking workload ({chunk}-instance passes), "
+               sample=f"{nb} cold-start tiny_solve calls on the first instances of the same workload ({chunk}-instance passes), "
                       f"{t:.1f} s, mean {mi:.1f} iterations, FTZ/DAZ off, g++ -O3 SSE2 (the build SURVEY.md probed)")
     # our multi-threaded C port on the host cores this process may use, for scale (not what the reference ships)
     try:
@@ -89,10 +115,22 @@ def cpu_baseline(prob, pr, seconds_target=12.0):
         ncores = os.cpu_count() or 1
     ncores = max(1, min(ncores, 16))
     port = O.Oracle(prob, np.float32)
-    nbp, tp, _ = timed(port, ncores, 4.0, 4096 * ncores)
+    nbp, tp, _, _ = timed(port, ncores, 4.0, max(64, min(4096, chunk)) * ncores)
     out["port_all_cores"] = dict(value=nbp / tp, unit="solves/s", cores=ncores, kind="port",
                                  sample=f"{nbp} solves, OpenMP over instances, {tp:.1f} s")
-    return out
+    return out, first, kind
+
+
+def parity_of(gpu_u, gpu_iter, gpu_status, ref, kind, u_scale):
+    """The bench line's own parity evidence: the first instances of the timed batch against the CPU reference's results
+    for the same inputs (computed by the cpu_baseline leg).  max_rel_u = max over instances of |u - u_ref|_inf /
+    max(|u_ref|_inf, input bound) (SURVEY.md §7 'Parity definition')."""
+    n = min(gpu_u.shape[0], ref["u"].shape[0])
+    g, r = gpu_u[:n].astype(np.float64).reshape(n, -1), ref["u"][:n].astype(np.float64).reshape(n, -1)
+    rel = np.max(np.abs(g - r), axis=1) / np.maximum(np.max(np.abs(r), axis=1), u_scale)
+    return dict(instances=int(n), max_rel_u=float(rel.max()), bitwise_u=bool(np.array_equal(gpu_u[:n], ref["u"][:n])),
+                iter_mismatch=int(np.sum(gpu_iter[:n] != ref["iter"][:n])), status_mismatch=int(np.sum(gpu_status[:n] != ref["status"][:n])),
+                against=f"cpu_baseline ({kind}) on the same inputs, whole horizon of u")
 
 
 def main():
@@ -100,23 +138,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--config", choices=list(CONFIGS), default="tracking",
+                    help="tracking = BASELINE.json configs[2], the headline (default); random32 = configs[3]: nx=32 nu=16 N=50, "
+                         "16384 instances in all, block-sharded over the ranks (strong scaling)")
+    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (tracking; default 65536) / in all (random32; default 16384)")
     ap.add_argument("--mode", choices=["early_exit", "fixed10"], default="early_exit")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto (rowlane exact), 1 streaming, 2 rowlane exact, 3 rowlane fast")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto (exact row / wave kernel), 1 streaming, 2 row exact, 3 row fast")
     ap.add_argument("--dispatch", type=int, choices=[0, 1], default=1,
                     help="workgroup dispatch order of the row kernel: 0 index order, 1 longest first by the predicted iteration count "
                          "(tiny_batch_set_dispatch; the predictor sweep and the sort run inside the timed region)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and with it the parity sample)")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the warm-started closed-loop and the pipelined-batches extras (profiling runs: "
                     "its launches of the same kernel would be averaged into the per-kernel statistics)")
     args = ap.parse_args()
 
-    import torch
-    import accelerated_tinympc_amd as T
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        # one process per GPU: N > 1 is launched by torch.distributed.run (see the module docstring); a lone process asked
+        # for N GPUs would silently measure one
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 as\n  python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...\n")
+        raise SystemExit(2)
+
+    import torch
+    import accelerated_tinympc_amd as T
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # rehearsal knobs (one-GPU box): TINYMPC_BENCH_DEVICE pins every rank to one device, TINYMPC_BENCH_BACKEND=gloo
@@ -132,22 +180,38 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    world_seen = dist.get_world_size() if dist is not None else 1
 
     pr = T.problems
-    prob = pr.quadrotor(20, N)
-    B = args.batch
-    # shard = contiguous block of the global instance index; weak scaling: B instances per rank
-    gx0, table, gstart = pr.tracking_batch(B * world, N)
-    lo, hi = T.sharding.block_partition(B * world, world, rank)
-    x0, start = gx0[lo:hi], gstart[lo:hi]
+    cfg = CONFIGS[args.config]
+    NX, NU, N = cfg["nx"], cfg["nu"], cfg["N"]
+    cost = Cost(NX, NU, N)
     settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1, en_state_bound=1, en_input_bound=1)
     if args.mode == "fixed10":
         settings.update(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=10)
+    # shard = contiguous block of the global instance index
+    if args.config == "tracking":
+        prob = pr.quadrotor(20, N)
+        per_gpu = args.batch or cfg["per_gpu"]
+        total = per_gpu * world                      # weak scaling: per_gpu instances on every rank
+        gx0, table, gstart = pr.tracking_batch(total, N)
+        make_batch = lambda nb: (gx0[:nb], pr.expand_windows(table, gstart[:nb], N))
+    else:
+        prob = pr.random_system(NX, NU, N, seed=1234)  # SURVEY.md §8(d) config 4; cache from the library's own tiny_riccati()
+        total = args.batch or cfg["total"]             # strong scaling: the 16 384 instances are divided over the ranks
+        gx0, xref0 = pr.random_batch(total, NX, N)
+        make_batch = lambda nb: (gx0[:nb], xref0)
+    lo, hi = T.sharding.block_partition(total, world, rank)
+    B = hi - lo
+    x0 = gx0[lo:hi]
     sol = T.TinyBatchSolver(prob, B, device=dev_index, settings=settings)
     if args.kernel:
         sol.select_kernel(args.kernel)
     sol.set_bounds(*pr.bounds_arrays(prob))
-    sol.set_xref_window(table, start)
+    if args.config == "tracking":
+        sol.set_xref_window(table, gstart[lo:hi])
+    else:
+        sol.set_xref(xref0)
     sol.set_dispatch(args.dispatch)
     d_x0 = torch.from_numpy(np.ascontiguousarray(x0)).cuda()
     lib, h = sol.lib, sol._h
@@ -166,7 +230,6 @@ def main():
         step()
     sol.synchronize()
     sol.enable_timing(True)
-    kernel_ms = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -174,42 +237,46 @@ def main():
     sol.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    kernel_ms.append(sol.last_solve_ms())  # events of the last timed step (recorded on the launch stream)
+    kernel_ms = [sol.last_solve_ms()]  # events of the last timed step (recorded by the library on its launch stream)
     # per-step kernel durations: a second, untimed pass with an event read after every step
     for _ in range(min(args.steps, 10)):
         step()
         kernel_ms.append(sol.last_solve_ms())
     n_unsolved = sol.wait()
     iters, status, _ = sol.get_status()
-    agg = T.sharding.reduce_stats(dist, "cuda" if backend == "nccl" else "cpu", iters, status, flops_of(iters, status), dt)
+    npar = min(B, 2048)
+    gpu_u = sol.get_u()[:npar].copy() if (rank == 0 and world == 1 and not args.no_cpu) else None  # parity sample, before the extras touch the workspace
+    agg = T.sharding.reduce_stats(dist, "cuda" if backend == "nccl" else "cpu", iters, status, cost.flops_of(iters, status), dt)
     dt = agg["wall_s"]  # max over ranks
     # optional epilogue of SURVEY.md §8(e), outside the timed region: every rank obtains u.col(0) of all instances with
     # one all-gather (nu floats per instance; RCCL over xGMI on the real runs).  Never allowed to break the bench line.
     gather = None
     if dist is not None:
         try:
-            d_u0 = torch.empty((B, NU), dtype=torch.float32, device="cuda")
+            cap = max(T.sharding.block_partition(total, world, r)[1] - T.sharding.block_partition(total, world, r)[0] for r in range(world))
+            d_u0 = torch.zeros((cap, NU), dtype=torch.float32, device="cuda")
             sol._check(lib.tiny_batch_get_u0_device(h, C.c_void_p(d_u0.data_ptr())))
             sol.synchronize()
             t_g = time.perf_counter()
             if backend == "nccl":
-                d_all = torch.empty((B * world, NU), dtype=torch.float32, device="cuda")
+                d_all = torch.empty((cap * world, NU), dtype=torch.float32, device="cuda")
                 dist.all_gather_into_tensor(d_all, d_u0)
                 torch.cuda.synchronize()
-                mine = d_all[rank * B:(rank + 1) * B]
+                mine = d_all[rank * cap:rank * cap + B]
             else:
-                outs = [torch.empty((B, NU), dtype=torch.float32) for _ in range(world)]
+                outs = [torch.empty((cap, NU), dtype=torch.float32) for _ in range(world)]
                 dist.all_gather(outs, d_u0.cpu())
-                mine = outs[rank].cuda()
-            gather = {"op": "all_gather of u.col(0)", "bytes_per_rank": B * NU * 4, "ms": (time.perf_counter() - t_g) * 1e3,
-                      "own_block_intact": bool(torch.equal(mine, d_u0))}
+                mine = outs[rank][:B].cuda()
+            gather = {"op": "all_gather of u.col(0)", "bytes_per_rank": cap * NU * 4, "ms": (time.perf_counter() - t_g) * 1e3,
+                      "own_block_intact": bool(torch.equal(mine, d_u0[:B]))}
         except Exception as e:  # noqa: BLE001
             gather = {"error": f"{type(e).__name__}: {e}"}
-    total_solves = B * world * args.steps
+    total_solves = total * args.steps
     value = total_solves / dt
+    extras_ok = rank == 0 and world == 1 and not args.kernel and args.config == "tracking"
     # the opt-in fma-chain arithmetic of the same kernel, for reference (not the headline: see DESIGN.md §3)
     fast = None
-    if rank == 0 and world == 1 and not args.kernel and sol.kernel_name().startswith("rowlane"):
+    if extras_ok and sol.kernel_name().startswith("rowlane"):
         sol.select_kernel(3)
         for _ in range(2):
             step()
@@ -219,7 +286,7 @@ def main():
             ms.append(sol.last_solve_ms())
         itf, stf, _ = sol.get_status()
         fast = dict(kernel=sol.kernel_name(), kernel_ms=float(np.mean(ms)), solves_per_s=B / (float(np.mean(ms)) * 1e-3),
-                    f32_frac=flops_of(itf, stf) / (float(np.mean(ms)) * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                    f32_frac=cost.flops_of(itf, stf) / (float(np.mean(ms)) * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                     mean_iters=float(itf.mean()), note="kernel time only; parity bar = the reference's own fp64/fp32 spread")
         sol.select_kernel(0)
 
@@ -228,11 +295,11 @@ def main():
     # the state staying on chip between solves (tiny_batch_mpc_run_async).
     # Reported as an extra; `value` stays the cold-start solve rate above.
     closed = None
-    if rank == 0 and world == 1 and not args.kernel and not args.no_closed_loop:
+    if extras_ok and not args.no_closed_loop:
         try:
             sol.reset_workspace()
             sol._check(lib.tiny_batch_set_x0_device(h, C.c_void_p(d_x0.data_ptr())))
-            sol.set_xref_window(table, start)
+            sol.set_xref_window(table, gstart[lo:hi])
             ksteps = 20
             sol.mpc_run_async(ksteps, 1)      # settles the warm start
             sol.synchronize()
@@ -251,13 +318,13 @@ def main():
     # few instances that need 2-4x the mean iteration count — overlaps the head of the next instead of leaving CUs idle.
     # Reported as an extra; `value` and the roofline above stay the plain one-launch-after-another numbers.
     pipelined = None
-    if rank == 0 and world == 1 and not args.kernel and not args.no_closed_loop:
+    if extras_ok and not args.no_closed_loop:
         sols, streams = [], [torch.cuda.Stream(), torch.cuda.Stream()]
         try:
             for strm in streams:
                 s2 = T.TinyBatchSolver(prob, B, device=dev_index, settings=settings)
                 s2.set_bounds(*pr.bounds_arrays(prob))
-                s2.set_xref_window(table, start)
+                s2.set_xref_window(table, gstart[lo:hi])
                 s2.set_dispatch(0)  # overlapping launches already fill the tail; the predictor sweep would only add work
                 s2.set_stream(strm.cuda_stream)
                 sols.append(s2)
@@ -289,16 +356,25 @@ def main():
 
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
-        fl = flops_of(iters, status)  # this rank's launch
-        t_mem = B * B_SOLVE / (PEAK_HBM_GBS * 1e9)
+        fl = cost.flops_of(iters, status)  # this rank's launch
+        t_mem = B * cost.b_solve / (PEAK_HBM_GBS * 1e9)
         t_flop = fl / (PEAK_F32_TFLOPS * 1e12)
-        hbm_ach = B * B_SOLVE / (k_ms * 1e-3) / 1e9
+        hbm_ach = B * cost.b_solve / (k_ms * 1e-3) / 1e9
         fl_ach = fl / (k_ms * 1e-3) / 1e12
-        traffic = None
+        # HBM bytes per launch from the PMC passes (tools/collect_profiles.sh -> profiles/hbm_traffic.json).  The figure is
+        # bound to the kernel sources it was measured on: after any change to csrc/ it is stale and reported as null.
+        traffic, traffic_note = None, "no PMC figure committed for this kernel/workload"
         tf = ROOT / "profiles" / "hbm_traffic.json"
         if tf.exists():
             try:
-                traffic = json.loads(tf.read_text()).get(f"{sol.kernel_name()}:{args.mode}:{B}")
+                ent = json.loads(tf.read_text()).get(f"{sol.kernel_name()}:{args.mode}:{B}")
+                if isinstance(ent, dict):
+                    if ent.get("csrc_sha") == kernel_source_sha():
+                        traffic, traffic_note = ent["bytes"], f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated; kernel sources {ent['csrc_sha']}"
+                    else:
+                        traffic_note = f"stale: measured on kernel sources {ent.get('csrc_sha')}, this build is {kernel_source_sha()}"
+                elif ent is not None:
+                    traffic_note = "stale: figure predates the source binding"
             except Exception:
                 traffic = None
         if t_flop >= t_mem:
@@ -307,6 +383,7 @@ def main():
         else:
             roof = dict(bound="hbm", achieved=hbm_ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm_ach / PEAK_HBM_GBS,
                         traffic=traffic)
+        roof["traffic_note"] = traffic_note
         mp = ROOT / "profiles" / "measured_peaks.json"
         if mp.exists():  # what the box itself reaches on plain instruction loops (tools/micro/peaks.hip), next to the datasheet peak
             try:
@@ -317,21 +394,28 @@ def main():
                                           "note": "exact arithmetic issues separately rounded v_mul + v_add: its own ceiling is the mul_add figure"}
             except Exception:
                 pass
-        roof.update(kernel=sol.kernel_name(), kernel_ms=k_ms, hbm_GBs=hbm_ach, hbm_frac=hbm_ach / PEAK_HBM_GBS,
-                    f32_TFLOPs=fl_ach, f32_frac=fl_ach / PEAK_F32_TFLOPS, alg_bytes_per_solve=B_SOLVE,
+        per_step = np.asarray(kernel_ms[1:] if len(kernel_ms) > 1 else kernel_ms)
+        roof.update(kernel=sol.kernel_name(), kernel_ms=k_ms,
+                    kernel_ms_per_step={"min": float(per_step.min()), "median": float(np.median(per_step)), "max": float(per_step.max()),
+                                        "n": int(per_step.size), "note": "hipEvent pair around the solve launch, one untimed step each"},
+                    hbm_GBs=hbm_ach, hbm_frac=hbm_ach / PEAK_HBM_GBS,
+                    f32_TFLOPs=fl_ach, f32_frac=fl_ach / PEAK_F32_TFLOPS, alg_bytes_per_solve=cost.b_solve,
+                    alg_flops_per_iteration={"forward_sweep_and_updates": cost.f_fwd, "backward_sweep": cost.f_bwd},
                     alg_flops_per_launch=fl, note="fp32 vector/MFMA peak 157.3 TFLOP/s; the path is not a dense "
                     "GEMM, 'mfma' here means the fp32 FMA roof (vector == f32-MFMA peak on gfx950)")
+        what = "quadrotor_tracking" if args.config == "tracking" else "codegen_random (seeded marginally stable system, SURVEY.md §8(d) config 4)"
         line = {
-            "metric": "MPC solves/sec (batched quadrotor nx=12,nu=4,N=30)", "value": value, "unit": "solves/s",
+            "metric": cfg["metric"], "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"quadrotor_tracking batched {B} instances per GPU, cold-start tiny_solve, "
-                                   f"{args.mode} (tol 1e-3, max_iter 100)" if args.mode == "early_exit" else
-                                   f"quadrotor_tracking batched {B} instances per GPU, cold-start tiny_solve, fixed 10 iterations",
-                       "nx": NX, "nu": NU, "N": N, "instances_per_gpu": B, "parallelism": f"batch-shard x{world}",
+            "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{what} batched {B} instances per GPU, cold-start tiny_solve, "
+                                   + (f"{args.mode} (tol 1e-3, max_iter 100)" if args.mode == "early_exit" else "fixed 10 iterations"),
+                       "nx": NX, "nu": NU, "N": N, "instances_per_gpu": B, "instances_total": total, "parallelism": f"batch-shard x{world}",
+                       "world_size_seen": world_seen, "backend": (backend if world > 1 else "none (single process)"),
                        "kernel": sol.kernel_name(),
-                       "dispatch": "longest first by predicted iteration count (predictor sweep + sort inside the timed region)"
-                                   if args.dispatch else "index order", "mean_iters": agg["sum_iters"] / agg["n_instances"],
+                       "dispatch": ("longest first by predicted iteration count (predictor sweep + sort inside the timed region)"
+                                    if args.dispatch and sol.kernel_name().startswith(("rowlane", "rowloop")) and B >= 16384 else "index order"),
+                       "mean_iters": agg["sum_iters"] / agg["n_instances"],
                        "max_iters": agg["max_iters"], "frac_converged": agg["n_converged"] / agg["n_instances"]},
             "roofline": roof,
         }
@@ -344,7 +428,9 @@ def main():
         if pipelined is not None:
             line["pipelined_batches"] = pipelined
         if not args.no_cpu and world == 1:  # rank 0 at N=1 only: the other ranks of a multi-GPU run would sit in the barrier
-            line["cpu_baseline"] = cpu_baseline(prob, pr)
+            cb, ref_first, kind = cpu_baseline(prob, make_batch)
+            line["cpu_baseline"] = cb
+            line["parity"] = parity_of(gpu_u, iters, status, ref_first, kind, max(abs(prob["u_max"]), abs(prob["u_min"])))
         print(json.dumps(line), flush=True)
     sol.close()
     if dist is not None:

@@ -155,6 +155,14 @@ def test_golden_vectors(tinympc, oracle_mod, variant, name):
         sol.close()
 
 
+def plant_of(prob):
+    """x1 = Adyn*x0 + Bdyn*u0 in the order of the examples' Eigen expression (quadrotor_hovering.cpp:110-111): the oracle's
+    restatement, pinned against the compiled expression in tests/test_oracle.py."""
+    from oracle import oracle as O
+    orc = O.Oracle(prob, np.float32)
+    return lambda x0, u0: orc.plant_step(np.atleast_2d(x0), np.atleast_2d(u0)).reshape(np.shape(x0))
+
+
 def test_golden_warm_start_chain(tinympc, variant):
     """Closed loop driven by the HIP solver itself from the k=0 live-in: state persists on the device between
     solves (warm start), reset_dual_variables() between them — quadrotor_hovering.cpp:90-114."""
@@ -162,7 +170,7 @@ def test_golden_warm_start_chain(tinympc, variant):
     meta, prob, solves, z = load_fixture("quad_hover_f32_N30")
     sol = make_solver(tinympc, prob, 1, solves[0]["settings"], solves[0]["xref"], variant)
     sol.set_state(solves[0]["pre"])
-    A, Bm = prob["Adyn"].astype(np.float32), prob["Bdyn"].astype(np.float32)
+    plant = plant_of(prob)
     x0 = solves[0]["pre"]["x"][:, 0].copy()
     iters, u0s = [], []
     for k in range(70):
@@ -171,7 +179,7 @@ def test_golden_warm_start_chain(tinympc, variant):
         sol.solve()
         u0 = sol.get_u()[:, 0]
         iters.append(int(sol.get_status()[0][0])); u0s.append(u0[0].copy())
-        x0 = (x0 @ A.T + u0 @ Bm.T).astype(np.float32)  # same plant arithmetic as tests/golden/make_golden.py
+        x0 = plant(x0, u0)  # the examples' plant step, as in tests/golden/make_golden.py
     ref_it = z["trace_iter"]
     if exact:  # the whole 70-step closed loop is reproduced bit for bit
         assert np.array_equal(np.array(iters), ref_it) and np.array_equal(np.array(u0s), z["trace_u0"])
@@ -641,7 +649,7 @@ def test_reference_wrapper_names_drive_the_hovering_loop():
     lib.set_xmin(fp(xmn), 0); lib.set_xmax(fp(xmx), 0); lib.set_umin(fp(umn), 0); lib.set_umax(fp(umx), 0)
     xref = np.ascontiguousarray(solves[0]["xref"], np.float32)
     lib.set_xref(fp(xref), 0)
-    A, Bm = prob["Adyn"].astype(np.float32), prob["Bdyn"].astype(np.float32)
+    plant = plant_of(prob)
     x0 = solves[0]["pre"]["x"][0, 0].copy()
     u = np.zeros((29, 4), np.float32)
     it, stt = C.c_int(), C.c_int()
@@ -653,7 +661,7 @@ def test_reference_wrapper_names_drive_the_hovering_loop():
         lib.get_u(fp(u), 0)
         assert lib.tiny_wrapper_last_status(C.byref(it), C.byref(stt)) == 0
         iters.append(it.value); u0s.append(u[0].copy())
-        x0 = (x0 @ A.T + u[0] @ Bm.T).astype(np.float32)
+        x0 = plant(x0, u[0])
     assert np.array_equal(np.array(iters), z["trace_iter"]) and np.array_equal(np.array(u0s), z["trace_u0"])
     lib.tiny_wrapper_teardown()
 
@@ -668,7 +676,7 @@ def test_native_names_tiny_solve_hovering_loop(tinympc):
     for k, arr in zip(("x_min", "x_max", "u_min", "u_max"), bounds_of(prob, np.float32)):
         ns.a[k][:] = arr
     ns.a["Xref"][:] = solves[0]["xref"]
-    A, Bm = prob["Adyn"].astype(np.float32), prob["Bdyn"].astype(np.float32)
+    plant = plant_of(prob)
     x0 = solves[0]["pre"]["x"][0, 0].copy()
     recorded = {s["k"]: s for s in solves}
     iters, u0s = [], []
@@ -683,7 +691,7 @@ def test_native_names_tiny_solve_hovering_loop(tinympc):
             for name in STATE_ORDER:
                 assert np.array_equal(ns.a[name], post[name][0]), f"step {k}: {name}"
             assert np.array_equal(ns.residuals, post["residuals"][0]) and ns.work.status == post["status"][0]
-        x0 = (x0 @ A.T + ns.a["u"][0] @ Bm.T).astype(np.float32)  # :110-111
+        x0 = plant(x0, ns.a["u"][0])  # :110-111
     assert np.array_equal(np.array(iters), z["trace_iter"]) and np.array_equal(np.array(u0s), z["trace_u0"])
 
 
@@ -1561,3 +1569,48 @@ def test_negative_window_advance_is_refused(tinympc):
     s.mpc_step_async(1)   # the handle stays usable
     assert s.get_status()[0].min() >= 1
     s.close()
+
+
+@pytest.mark.parametrize("B", [2048, 16384])
+def test_config4_full_size_properties(tinympc, oracle_mod, B):
+    """BASELINE.json configs[3] at its stated sizes — nx=32, nu=16, N=50, 16 384 instances on one GPU and the 2 048 one of
+    eight GPUs receives (the bench.py --config random32 workload) — on the exact kernel that
+    serves the class; the two sizes run the kernel's two instantiations (look-ahead 4 at <= 2 048 instances, look-ahead 1
+    above).  Size-independent properties (duplicates, determinism, invariants, rollout consistency) plus a bitwise
+    comparison with the oracle on a sample spread over the whole batch."""
+    O, pr = oracle_mod, tinympc.problems
+    prob = pr.random_system(32, 16, 50, seed=1234)
+    nx, nu, N = 32, 16, 50
+    bnds = pr.bounds_arrays(prob)
+    x0, xref = pr.random_batch(B, nx, N)
+    half = B // 2
+    x0[half:] = x0[:half]
+    sol = tinympc.TinyBatchSolver(prob, B)
+    assert sol.kernel_name().endswith("exact>") and "32,16" in sol.kernel_name(), sol.kernel_name()
+    sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
+    rc = sol.solve()
+    a = sol.get_state()
+    for k in STATE_ORDER + SCALARS:                       # (1) duplicates agree wherever they sit
+        assert np.array_equal(a[k][:half], a[k][half:]), k
+    sol.reset_workspace(); sol.set_x0(x0); sol.solve()    # (2) determinism
+    b = sol.get_state()
+    for k in STATE_ORDER + SCALARS:
+        assert np.array_equal(a[k], b[k]), k
+    s = sol.settings                                      # (3) invariants
+    solved = a["status"] == 1
+    assert set(np.unique(a["status"])) <= {1, 11} and a["iter"].min() >= 1 and a["iter"].max() <= s["max_iter"]
+    assert rc == (0 if solved.all() else 1) and 0.05 < solved.mean() < 1.0   # the workload has both kinds of instance
+    assert np.all(a["residuals"][solved][:, :2] < s["abs_pri_tol"]) and np.all(a["residuals"][solved][:, 2:] < s["abs_dua_tol"])
+    assert np.all(a["iter"][~solved] == s["max_iter"])
+    assert a["znew"].max() <= prob["u_max"] and a["znew"].min() >= prob["u_min"]
+    assert a["vnew"].max() <= prob["x_max"] and a["vnew"].min() >= prob["x_min"]
+    assert np.array_equal(a["x"][:, 0], x0)
+    assert np.array_equal(a["v"][~solved], a["vnew"][~solved]) and np.array_equal(a["z"][~solved], a["znew"][~solved])
+    idx = np.arange(0, B, max(1, B // 256))
+    xs, us = a["x"][idx].astype(np.float64), a["u"][idx].astype(np.float64)
+    assert np.max(np.abs(xs[:, :-1] @ prob["Adyn"].T + us @ prob["Bdyn"].T - xs[:, 1:])) < 2e-4
+    st = O.new_state(idx.size, nx, nu, N)                 # (4) sampled bitwise comparison with the oracle
+    st["x"][:, 0] = x0[idx]
+    O.Oracle(prob, np.float32, s).solve(st, *bnds, xref, nthreads=8)
+    assert_bitwise({k: a[k][idx] for k in STATE_ORDER + SCALARS}, st, f"config 4, B={B}, {sol.kernel_name()}")
+    sol.close()

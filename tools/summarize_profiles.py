@@ -69,9 +69,14 @@ def label(kname):
     if m and m.group(6) != "true":   # the closed-loop (MPC) instantiation is a different workload
         return f"rowlane<{m.group(1)},{m.group(2)},{m.group(3)},{'exact' if m.group(4) == 'true' else 'fast'}{',h16' if m.group(5) == 'true' else ''}>"
     m = re.search(r"admm_stream_kernel<(\d+), (\d+)>", kname)
-    return f"stream<{m.group(1)},{m.group(2)}>" if m else kname
+    if m:
+        return f"stream<{m.group(1)},{m.group(2)}>"
+    m = re.search(r"admm_wave\w*_kernel<(\d+), (\d+)", kname)
+    return f"wavestream<{m.group(1)},{m.group(2)},exact>" if m else kname
 if line:
+    sys.path.insert(0, str(ROOT))
+    from bench import kernel_source_sha  # binds the figure to the kernel sources it was measured on (bench.py reports null once they change)
     for k, d in kern.items():
-        table[f"{label(k)}:early_exit:{line['config']['instances_per_gpu']}"] = d["hbm_bytes"]
+        table[f"{label(k)}:early_exit:{line['config']['instances_per_gpu']}"] = {"bytes": d["hbm_bytes"], "csrc_sha": kernel_source_sha(), "profile": tag}
 tf.write_text(json.dumps(table, indent=1))
 print(json.dumps({k: v for k, v in out.items() if k != "bench_line_under_profiler"}, indent=1)[:3000])
