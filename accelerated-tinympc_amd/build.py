@@ -16,12 +16,16 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libtinympc_hip.so"
 WRAPPER_LIB = PKG / "lib" / "libtinympc_wrapper.so"  # same-name twin of the reference's generated wrapper library
-SOURCES = ["tinympc_batch.hip", "admm_stream.hip", "admm_rowlane.hip", "admm_rowloop.hip", "admm_quadlane.hip", "admm_wave.hip", "admm_steps.hip", "dispatch_order.hip", "riccati.cpp"]
+SOURCES = ["tinympc_batch.hip", "admm_stream.hip", "admm_rowlane.hip", "admm_rowloop.hip", "admm_quadlane.hip", "admm_tile16.hip", "admm_wave.hip", "admm_steps.hip", "dispatch_order.hip", "riccati.cpp"]
 WRAPPER_SRCS = [CSRC / "wrapper_compat.cpp", CSRC / "admm_compat.cpp"]
 HEADERS = [CSRC / "tinympc_internal.h", CSRC / "rowlane_math.h", CSRC / "tile_math.h", CSRC / "dpp_ops_gen.h", PKG.parent / "include" / "tinympc_batch.h"]
 # -ffp-contract=off : exact arithmetic must not fuse a*b+c; the fast paths call fma explicitly
 # -fno-slp-vectorize: hipcc otherwise pairs scalar fp32 adds into v_pk_add_f32 (+ v_mov to build the pairs), which on
 #                     gfx950 is slower than two plain v_add_f32 (measured, tools/micro/*.hip)
+# per-file extras.  admm_tile16.hip: MFMA results go to VGPRs (the sums that consume the exact products are VALU instructions,
+# which cannot read the accumulator half of the register file: left to its heuristics hipcc parks the products there and
+# copies every one of them back, 110 v_accvgpr_read per horizon step)
+EXTRA_FLAGS = {"admm_tile16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-gpu-rdc"]
 
 
@@ -48,7 +52,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     for src, obj in _objs():
         if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_t):
             continue
-        cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))

@@ -5,6 +5,13 @@
 #include "tinympc_internal.h"
 #include "dpp_ops_gen.h"
 
+#ifndef TINY_OPT_SEL
+#define TINY_OPT_SEL 0
+#endif
+#ifndef TINY_OPT_DDNOW
+#define TINY_OPT_DDNOW 0
+#endif
+
 namespace tinympc
 {
 
@@ -255,13 +262,30 @@ __device__ __forceinline__ void riccati_step(const RowGains<NX, NU> &G, bool is_
         dpp_products<0, NX>(t, p, G.M3);
         float dot;
         if constexpr (PL::BWD_PA == PL::BWD_TMP) dot = reduce<PL::BWD_PA>(t);
-        else dot = is_x ? reduce<PL::BWD_PA>(t) : reduce<PL::BWD_TMP>(t);
+        else
+        {
+#if TINY_OPT_SEL
+            // x rows and u rows sum the same products in different orders.  Both sums are computed by every lane and
+            // selected: left to itself hipcc turns the select into two EXEC-masked branches (one dependent chain each,
+            // nothing to overlap them with, 7 scalar instructions per step around them)
+            float rx = reduce<PL::BWD_PA>(t), ru = reduce<PL::BWD_TMP>(t);
+            asm volatile("" : "+v"(rx), "+v"(ru));
+            dot = is_x ? rx : ru;
+#else
+            dot = is_x ? reduce<PL::BWD_PA>(t) : reduce<PL::BWD_TMP>(t);
+#endif
+        }
         const float wv = lin + dot;            // q + AmBKt*p  |  Bdyn^T*p + r
         float tk[NU], td[NU];
         dpp_products<NX, NU>(tk, lin, G.M45);  // Kinf^T * r
         dpp_products<NX, NU>(td, wv, G.M45);   // Quu_inv * (Bdyn^T p + r)
         pn = rnd<H16>(wv - reduce<PL::BWD_PK>(tk));
         dd = rnd<H16>(reduce<PL::BWD_D>(td));
+#if TINY_OPT_DDNOW
+        // d_i is off the critical chain of the sweep: without this hipcc postpones its three adds to the end of the sweep
+        // and keeps (spills) the four products of every step until then
+        asm volatile("" : "+v"(dd));
+#endif
     }
     else
     {

@@ -235,6 +235,7 @@ struct TinyBatch
     int NXC = 0, NUC = 0, ntiles = 0, bpad4 = 0;
     int rw = 16; // lanes per instance-step of the ROW layout
     bool row_dims_ok = false, tile_dims_ok = false, rowmath_ok = false, rowloop_ok = false, wave_ok = false, quad_ok = false;
+    bool tile16_ok = false; // admm_tile16.hip has an instantiation for (nx, nu, N)
     int *conv_dev = nullptr; // [batch] result of termination_condition
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr; // created by tiny_batch_group_solve / mpc_run for handles left on the null stream
@@ -740,6 +741,10 @@ int row_family(const TinyBatch *tb)
     if (tb->wave_ok) return 3; // one wavefront per instance, state in HBM (admm_wave.hip)
     if (!bounds_all_shared(tb)) return 2; // per-instance bounds: only the streaming row kernel reads them per instance
     if (tb->en_uref || tb->en_d2p) return 2; // the optional terms live in the streaming row kernel (c's u rows hold d elsewhere)
+    // 5 = sixteen instances per wave, products on the matrix cores (admm_tile16.hip): on request only; needs fp32 storage and
+    // a reference it does not have to keep resident (window of a table, or one shared reference)
+    if (tb->row_family_forced == 5)
+        return (tb->tile16_ok && !tb->h16 && (tb->xref_mode == 1 || !tb->in_xref.set || tb->in_xref.shared)) ? 5 : (tb->row_dims_ok ? 0 : (tb->rowloop_ok ? 1 : 2));
     if (tb->row_family_forced >= 0) return tb->row_family_forced;
     if (tb->quad_ok) return 4; // four lanes per instance (admm_quadlane.hip): nx = 4, nu = 1
     if (tb->row_dims_ok) return 0;
@@ -759,6 +764,7 @@ void update_kname(TinyBatch *tb)
     else if (row_family(tb) == 1) snprintf(nm, sizeof nm, "rowloop<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
     else if (row_family(tb) == 3) snprintf(nm, sizeof nm, "wavestream<%d,%d,%s>", tb->nx, tb->nu, ar);
     else if (row_family(tb) == 4) snprintf(nm, sizeof nm, "quadlane<%d,%d,%d,%s%s>", tb->nx, tb->nu, tb->N, ar, sto);
+    else if (row_family(tb) == 5) snprintf(nm, sizeof nm, "tile16<%d,%d,%d,%s>", tb->nx, tb->nu, tb->N, ar);
     else snprintf(nm, sizeof nm, "rowstream<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
     tb->kname = nm;
 }
@@ -918,6 +924,7 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
             : fam == 1 ? launch_admm_rowloop(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
             : fam == 3 ? launch_admm_wavestream(tb->nx, tb->nu, P, tb->stream)
             : fam == 4 ? launch_admm_quadlane(tb->N, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
+            : fam == 5 ? launch_admm_tile16(tb->N, v == VAR_ROW_EXACT, P, tb->stream)
                        : launch_admm_rowstream(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream);
     }
     if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -996,6 +1003,7 @@ int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int dev
     tb->rowloop_ok = tb->rowmath_ok && rowloop_supported(nx, nu, N);
     tb->wave_ok = wave_ok;
     tb->quad_ok = tb->rowmath_ok && quadlane_supported(nx, nu, N);
+    tb->tile16_ok = tb->rowmath_ok && tile16_supported(nx, nu, N);
     tb->rw = wave_ok ? 64 : 16;
     tb->xfam_floats = (size_t)tb->ntiles * N * WAVE * nxc;
     tb->ufam_floats = (size_t)tb->ntiles * (N - 1) * WAVE * nuc;
@@ -1548,13 +1556,13 @@ const char *tiny_batch_kernel_name(TinyBatch *tb)
 int tiny_batch_set_row_kernel(TinyBatch *tb, int family)
 {
     CHECK_TB(tb);
-    if (family < 0 || family > 4)
-        return fail(TINY_BATCH_EINVAL, "row kernel must be 0 (auto), 1 (rowlane), 2 (rowloop), 3 (rowstream) or 4 (quadlane)");
+    if (family < 0 || family > 5)
+        return fail(TINY_BATCH_EINVAL, "row kernel must be 0 (auto), 1 (rowlane), 2 (rowloop), 3 (rowstream), 4 (quadlane) or 5 (tile16)");
     const bool ok = family == 0 || (family == 1 && tb->row_dims_ok) || (family == 2 && tb->rowloop_ok) || (family == 3 && tb->rowmath_ok) ||
-                    (family == 4 && tb->quad_ok);
+                    (family == 4 && tb->quad_ok) || (family == 5 && tb->tile16_ok);
     if (!ok)
         return fail(TINY_BATCH_EUNSUPPORTED, "row kernel %d has no instantiation for nx=%d nu=%d N=%d", family, tb->nx, tb->nu, tb->N);
-    static const int kFam[5] = {-1, 0, 1, 2, 4};
+    static const int kFam[6] = {-1, 0, 1, 2, 4, 5};
     tb->row_family_forced = kFam[family];
     invalidate_graph(tb);
     return 0;

@@ -133,6 +133,11 @@ hipError_t launch_admm_rowloop(int nx, int nu, bool exact, bool h16, const RowPa
 bool quadlane_supported(int nx, int nu, int N);
 hipError_t launch_admm_quadlane(int N, bool exact, bool h16, const RowParams &P, hipStream_t stream);
 
+// sixteen-instances-per-wave register-resident kernel with the products on the matrix cores (admm_tile16.hip): nx = 12, nu = 4,
+// instantiated horizons; ROW layout and RowParams of the row kernels; shared bounds, window / shared reference, fp32 storage
+bool tile16_supported(int nx, int nu, int N);
+hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t stream);
+
 // wave-per-instance exact kernel (admm_wave.hip): 16 < nx + nu <= 64, any N, state in HBM, row width 64
 #define TINY_FOR_EACH_WAVEDIMS(X) X(32, 16) X(16, 8) X(16, 4)
 bool wavedims_supported(int nx, int nu);

@@ -13,6 +13,8 @@ from pathlib import Path
 
 import numpy as np
 
+import os
+
 from . import build as _build
 
 PKG = Path(__file__).resolve().parent
@@ -40,7 +42,8 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         else:
             raise TinyBatchError(f"{LIB_PATH} is missing: run `python accelerated-tinympc_amd/build.py` "
                                  "(hipcc --offload-arch=gfx950); there is no CPU fallback")
-    lib = C.CDLL(str(LIB_PATH))
+    # developer aid: TINYMPC_HIP_LIB names another build of the SAME library (tools/ab_kernels.py times kernel variants)
+    lib = C.CDLL(os.environ.get("TINYMPC_HIP_LIB") or str(LIB_PATH))
     F, I, P = C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p
     D = C.POINTER(C.c_double)
     sig = {
@@ -350,7 +353,8 @@ class TinyBatchSolver:
         self._check(self.lib.tiny_batch_select_kernel(self._h, variant))
 
     def set_row_kernel(self, family: int):
-        """0 auto, 1 rowlane (unrolled), 2 rowloop (rolled, N <= 32), 3 rowstream (state in HBM), 4 quadlane (nx=4, nu=1)."""
+        """0 auto, 1 rowlane (unrolled), 2 rowloop (rolled, N <= 32), 3 rowstream (state in HBM), 4 quadlane (nx=4, nu=1),
+        5 tile16 (16 instances per wave, products on the matrix cores; nx=12, nu=4, instantiated N)."""
         self._check(self.lib.tiny_batch_set_row_kernel(self._h, family))
 
     def set_dispatch(self, mode: int):

@@ -36,7 +36,10 @@ SCALARS = ("iter", "status", "residuals")
 # kernel variants under test: (select_kernel id, exact?, set_row_kernel family: 0 auto = rowlane where instantiated)
 VARIANTS = {"row_exact": (2, True, 0), "row_fast": (3, False, 0), "stream": (1, False, 0),
             "loop_exact": (2, True, 2), "loop_fast": (3, False, 2), "rowstream_exact": (2, True, 3),
-            "lane_exact": (2, True, 1)}  # auto prefers quadlane for nx=4, nu=1: keep the 16-lane kernel covered there too
+            "lane_exact": (2, True, 1),  # auto prefers quadlane for nx=4, nu=1: keep the 16-lane kernel covered there too
+            # 16 instances per wave, products on the matrix cores (admm_tile16.hip; quadrotor N=30 only): exact = K=1 MFMA products
+            # + reference-order sums, bitwise like the row kernels; fma = MFMA chains, bitwise equal to the row kernels' fma mode
+            "tile_exact": (2, True, 5), "tile_fast": (3, False, 5)}
 
 
 def _floor(name, prob, ref):
@@ -1614,3 +1617,65 @@ def test_config4_full_size_properties(tinympc, oracle_mod, B):
     O.Oracle(prob, np.float32, s).solve(st, *bnds, xref, nthreads=8)
     assert_bitwise({k: a[k][idx] for k in STATE_ORDER + SCALARS}, st, f"config 4, B={B}, {sol.kernel_name()}")
     sol.close()
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_tile16_kernel_equals_row_kernel_bitwise(tinympc, oracle_mod, exact):
+    """admm_tile16.hip (16 instances per wavefront as MFMA columns, set_row_kernel(5)) against the 16-lane row kernel on the
+    same inputs: ragged batches around its 16-instance tile and 4-tile workgroup, cold and warm starts, sparse termination
+    checks, one and zero iterations, bounds off, shared reference and window reference with clamping at the end of the
+    table.  Both arithmetic modes must agree BIT FOR BIT with the row kernel (exact: K=1 MFMA products are separately
+    rounded products; fma: v_mfma_f32_16x16x4_f32 is the same k-ascending fma chain as the row kernel's v_fmac_f32_dpp),
+    and the exact mode with the oracle."""
+    O, pr = oracle_mod, tinympc.problems
+    prob = pr.quadrotor(20, 30)
+    bnds = pr.bounds_arrays(prob)
+    for B, settings, warm, ref in ((1, {}, 1, "window"), (15, {}, 0, "shared"), (16, dict(max_iter=7), 0, "window"), (17, {}, 2, "window"),
+                                   (63, dict(max_iter=40, check_termination=3), 1, "window"), (65, dict(max_iter=1), 0, "window"),
+                                   (130, dict(max_iter=0), 0, "window"), (333, dict(max_iter=30, en_state_bound=0, en_input_bound=0), 1, "endclamp"),
+                                   (3000, {}, 0, "window")):
+        settings = dict(O.DEFAULT_SETTINGS, **settings)
+        x0, table, start = pr.tracking_batch(B, 30, seed=B)
+        if ref == "endclamp":
+            start = np.minimum(start + 200, 301 - 30).astype(np.int32)
+        outs = []
+        for fam in (1, 5):
+            sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+            sol.select_kernel(2 if exact else 3); sol.set_row_kernel(fam)
+            sol.set_bounds(*bnds)
+            if ref == "shared":
+                sol.set_xref(np.tile(pr.HOVER_XREF, (30, 1)).astype(np.float32))
+            else:
+                sol.set_xref_window(table, start)
+            assert sol.kernel_name().startswith("tile16<12,4,30" if fam == 5 else "rowlane<12,4,30"), sol.kernel_name()
+            sol.set_x0(x0)
+            rcs = [sol.solve()]
+            for _ in range(warm):
+                if ref != "shared":
+                    sol.mpc_step_async(1)           # plant step + window slide + dual reset + solve (graph-free path)
+                else:
+                    sol.reset_dual_variables(); rcs.append(sol.solve())
+            outs.append((rcs, sol.get_state(), sol.get_x0()))
+            sol.close()
+        (r1, a, xa), (r5, b, xb) = outs
+        assert r1 == r5 and np.array_equal(xa, xb)
+        assert_bitwise(b, a, f"tile16 vs rowlane, exact={exact}, B={B}, {settings}, warm={warm}, {ref}")
+        if exact and warm == 0 and B <= 400:
+            st = O.new_state(B, 12, 4, 30); st["x"][:, 0] = x0
+            xr = np.tile(pr.HOVER_XREF, (30, 1)).astype(np.float32) if ref == "shared" else pr.expand_windows(table, start, 30)
+            O.Oracle(prob, np.float32, settings).solve(st, *bnds, xr, nthreads=8)
+            if settings["max_iter"] > 0:
+                assert_bitwise(b, st, f"tile16 exact vs oracle, B={B}, {settings}")
+    # a per-instance reference array cannot stay resident: the handle falls back to the row kernel, results unchanged
+    sol = tinympc.TinyBatchSolver(prob, 20)
+    sol.set_row_kernel(5); sol.set_bounds(*bnds)
+    x0, table, start = pr.tracking_batch(20, 30, seed=2)
+    sol.set_xref(pr.expand_windows(table, start, 30))
+    assert sol.kernel_name().startswith("rowlane<12,4,30"), sol.kernel_name()
+    sol.close()
+    with pytest.raises(tinympc.TinyBatchError):
+        s2 = tinympc.TinyBatchSolver(pr.cartpole(10), 4)
+        try:
+            s2.set_row_kernel(5)
+        finally:
+            s2.close()
