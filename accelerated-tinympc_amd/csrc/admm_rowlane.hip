@@ -28,7 +28,15 @@ namespace tinympc
 
 // MPC = true: the closed-loop variant (P.mpc_steps MPC steps inside one launch); a separate instantiation so that the
 // ordinary solve keeps its register allocation
-template <int NX, int NU, int N, bool EXACT, bool H16, bool MPC = false>
+// BPI = true: box bounds per instance (every reference workspace owns its u_min .. x_max, types.hpp:88-91): the {lo, hi}
+// pair of a lane-step comes from the [B][N][16] table in global memory, BPI_AHEAD steps ahead of its use (8 bytes per lane
+// and step; the 3.8 KB of an instance are re-read every iteration and stay in L2 / the Infinity Cache), instead of from the
+// one table the batch shares in LDS
+#ifndef TINY_BPI_AHEAD
+#define TINY_BPI_AHEAD 4
+#endif
+constexpr int BPI_AHEAD = TINY_BPI_AHEAD;
+template <int NX, int NU, int N, bool EXACT, bool H16, bool MPC = false, bool BPI = false>
 __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P)
 {
     const int lane = threadIdx.x;
@@ -45,13 +53,17 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
     const float rho = P.rho;
 
     // ---- box bounds of the whole horizon, shared by the batch: LDS table [N][16] of {lo, hi} ----
-    __shared__ float2 bnd[N * 16];
+    __shared__ float2 bnd[BPI ? 1 : N * 16];
     // vnew/znew of the current sweep (sn) and the previous slack v/z (b) live in LDS (lane-linear => conflict free):
     // each is written once and read once per iteration, so they do not need a VGPR per horizon step.
     __shared__ float sn_lds[N * WAVE];
     __shared__ float b_lds[N * WAVE];
-    for (int e = lane; e < N * 16; e += WAVE) bnd[e] = ld_bounds<H16>(P.bounds, e);
-    __syncthreads();
+    if constexpr (!BPI)
+    {
+        for (int e = lane; e < N * 16; e += WAVE) bnd[e] = ld_bounds<H16>(P.bounds, e);
+        __syncthreads();
+    }
+    const int bbase = BPI ? inst_a * (int)P.bounds_inst_stride + r16 : 0; // {lo,hi} entry of step i: bbase + i*16
     float *sn = sn_lds + lane;   // sn[i * WAVE]
     float *b = b_lds + lane;     // b[i * WAVE]
 
@@ -130,12 +142,25 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
         {
             // ---------------- forward sweep: forward_pass + update_slack + update_dual + residual maxima ----------------
             float s = x0, pri = 0.f, dua = 0.f;
-            float2 lh = bnd[r16];
+            float2 lh, lhq[BPI_AHEAD];
+            if constexpr (BPI)
+            {
+#pragma unroll
+                for (int k = 0; k < BPI_AHEAD; k++) lhq[k] = ld_bounds<H16>(P.bounds, bbase + (k < N ? k : N - 1) * 16);
+                lh = lhq[0];
+            }
+            else lh = bnd[r16];
             float b_pref = b[0];
 #pragma unroll
             for (int i = 0; i < N; i++)
             {
-                const float2 lh_next = bnd[(i + 1 < N ? i + 1 : i) * 16 + r16]; // LDS reads one step ahead
+                float2 lh_next;
+                if constexpr (BPI)
+                {
+                    if (i + BPI_AHEAD < N) lhq[i % BPI_AHEAD] = ld_bounds<H16>(P.bounds, bbase + (i + BPI_AHEAD) * 16); // its slot was consumed by step i
+                    lh_next = lhq[(i + 1) % BPI_AHEAD];
+                }
+                else lh_next = bnd[(i + 1 < N ? i + 1 : i) * 16 + r16]; // LDS reads one step ahead
                 const float b_next = b[(i + 1 < N ? i + 1 : i) * WAVE];
                 float sv, xn = 0.f;
                 if (i < N - 1) lqr(s, c[i], sv, xn);
@@ -292,9 +317,9 @@ bool rowlane_supported(int nx, int nu, int N)
 hipError_t launch_admm_rowlane(int nx, int nu, int N, bool exact, bool h16, const RowParams &P, hipStream_t stream)
 {
     const int nblocks = (P.batch + 3) / 4;
-    if (P.mpc_steps > 1) // closed loop on chip: fp32 storage only
+    if (P.mpc_steps > 1) // closed loop on chip: fp32 storage and batch-shared bounds only
     {
-        if (h16) return hipErrorInvalidValue;
+        if (h16 || P.bounds_inst_stride != 0) return hipErrorInvalidValue;
 #define TINY_ROWLANE_MPC_DISPATCH(NX, NU, NN)                                                               \
     if (nx == NX && nu == NU && N == NN)                                                                    \
     {                                                                                                       \
@@ -303,6 +328,19 @@ hipError_t launch_admm_rowlane(int nx, int nu, int N, bool exact, bool h16, cons
         return hipGetLastError();                                                                           \
     }
         TINY_FOR_EACH_ROWLANE(TINY_ROWLANE_MPC_DISPATCH)
+        return hipErrorInvalidValue;
+    }
+    if (P.bounds_inst_stride != 0) // per-instance bounds: fp32 storage only (fp16 storage with them runs on the streaming row kernel)
+    {
+        if (h16) return hipErrorInvalidValue;
+#define TINY_ROWLANE_BPI_DISPATCH(NX, NU, NN)                                                                            \
+    if (nx == NX && nu == NU && N == NN)                                                                                 \
+    {                                                                                                                    \
+        if (exact) hipLaunchKernelGGL((admm_rowlane_kernel<NX, NU, NN, true, false, false, true>), dim3(nblocks), dim3(WAVE), 0, stream, P);  \
+        else hipLaunchKernelGGL((admm_rowlane_kernel<NX, NU, NN, false, false, false, true>), dim3(nblocks), dim3(WAVE), 0, stream, P);      \
+        return hipGetLastError();                                                                                        \
+    }
+        TINY_FOR_EACH_ROWLANE(TINY_ROWLANE_BPI_DISPATCH)
         return hipErrorInvalidValue;
     }
 #define TINY_ROWLANE_LAUNCH(NX, NU, NN, EX, H) \

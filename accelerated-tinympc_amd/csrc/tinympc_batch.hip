@@ -739,7 +739,10 @@ int resolve_variant(TinyBatch *tb, int *out)
 int row_family(const TinyBatch *tb)
 {
     if (tb->wave_ok) return 3; // one wavefront per instance, state in HBM (admm_wave.hip)
-    if (!bounds_all_shared(tb)) return 2; // per-instance bounds: only the streaming row kernel reads them per instance
+    // per-instance bounds: the unrolled register-resident kernel reads them from the [B][N][16] table (fp32 storage), the
+    // streaming row kernel serves every other case; the rolled-loop and quad kernels stage one shared table in LDS
+    if (!bounds_all_shared(tb))
+        return (tb->row_dims_ok && !tb->h16 && !tb->en_uref && !tb->en_d2p && (tb->row_family_forced < 0 || tb->row_family_forced == 0)) ? 0 : 2;
     if (tb->en_uref || tb->en_d2p) return 2; // the optional terms live in the streaming row kernel (c's u rows hold d elsewhere)
     // 5 = sixteen instances per wave, products on the matrix cores (admm_tile16.hip): on request only; needs fp32 storage and
     // a reference it does not have to keep resident (window of a table, or one shared reference)
@@ -1459,7 +1462,7 @@ int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, 
     TRY(prepare_solve(tb, &v));
     const size_t u0n = (size_t)tb->batch * tb->nu;
     const int fam = v != VAR_STREAM ? row_family(tb) : -1;
-    if ((fam == 0 || fam == 4) && !tb->h16 && steps > 1)
+    if ((fam == 0 || fam == 4) && !tb->h16 && steps > 1 && bounds_all_shared(tb))
     {
         RowParams P;
         fill_row_params(tb, P, v == VAR_ROW_EXACT);
