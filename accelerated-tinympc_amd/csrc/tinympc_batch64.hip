@@ -1,0 +1,615 @@
+// tinympc_batch64.hip — the batched TinyMPC ADMM solver for `typedef double tinytype` (the reference as shipped,
+// src/tinympc/glob_opts.hpp:3): C-ABI of include/tinympc_batch64.h, device workspace, and the kernel.
+//
+// One thread per instance, state in HBM.  Every per-instance array is stored instance-minor — element (step, row) of
+// instance b at ((step * dim + row) * Bpad + b) — so that the 64 instances of a wavefront read and write 512 contiguous
+// bytes per element.  One launch runs all ADMM iterations; a converged instance stops storing exactly where the reference
+// returns (admm.cpp:135-137: before the v/z copy and the backward pass).
+//
+// Arithmetic: tiny_solve() of the reference (admm.cpp:15-152) statement by statement, every product and sum a separately
+// rounded fp64 operation (the library is built with -ffp-contract=off), summed in the order of the reference's SSE2 Eigen
+// build, whose packets hold PS = 2 doubles: sequential for packet-evaluated lazy products (result rows a multiple of 2),
+// halving tree for coefficient-evaluated ones, packet tree + s0 + s1 for vectorised reductions.  Results are bitwise equal
+// to the compiled reference (tests/test_parity_gpu.py: golden vectors of the as-shipped fp64 N = 10 hovering run).
+// There is no CPU fallback.
+#include "../../include/tinympc_batch64.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace
+{
+
+constexpr int PS = 2; // doubles per SSE2 packet
+constexpr int WAVE64 = 64;
+constexpr int ST_SOLVED = 1, ST_UNSOLVED = 11; // admm.cpp:136, :114
+
+// ---- reductions in the reference's orders (Eigen 3.4.90: redux_novec_unroller, redux_vec_unroller, etor_product_packet_impl) ----
+template <int LO, int CNT, int NN>
+__device__ __forceinline__ double tree_sum(const double (&t)[NN])
+{
+    if constexpr (CNT == 1) return t[LO];
+    else
+    {
+        constexpr int H = CNT / 2;
+        return tree_sum<LO, H>(t) + tree_sum<LO + H, CNT - H>(t);
+    }
+}
+template <int PLO, int PCNT, int L, int NN>
+__device__ __forceinline__ double ptree_sum(const double (&t)[NN]) // lane L of the packets [PLO, PLO + PCNT)
+{
+    if constexpr (PCNT == 1) return t[PS * PLO + L];
+    else
+    {
+        constexpr int H = PCNT / 2;
+        return ptree_sum<PLO, H, L>(t) + ptree_sum<PLO + H, PCNT - H, L>(t);
+    }
+}
+template <int NN>
+__device__ __forceinline__ double seq_sum(const double (&t)[NN])
+{
+    double acc = t[0];
+#pragma unroll
+    for (int k = 1; k < NN; k++) acc = acc + t[k];
+    return acc;
+}
+template <int NN>
+__device__ __forceinline__ double novec_sum(const double (&t)[NN])
+{
+    if constexpr (NN == 1) return t[0];
+    else if constexpr (3 * NN - 1 <= 110) return tree_sum<0, NN>(t);
+    else return seq_sum(t);
+}
+template <int NN>
+__device__ __forceinline__ double vec_sum(const double (&t)[NN])
+{
+    static_assert(3 * NN - 1 <= 110 * PS, "beyond Eigen's unrolling limit the order is not restated");
+    if constexpr (NN < PS) return novec_sum(t);
+    else
+    {
+        constexpr int NPK = NN / PS;
+        double res = ptree_sum<0, NPK, 0>(t) + ptree_sum<0, NPK, 1>(t); // predux of a 2-double packet
+        if constexpr (NN % PS != 0) res = res + tree_sum<PS * NPK, NN - PS * NPK>(t);
+        return res;
+    }
+}
+// (row i of a column-major ROWS x COLS matrix) . xin, as a lazy product whose result has ROWS rows
+template <int ROWS, int COLS>
+__device__ __forceinline__ double row_dot(const double *M, int i, const double (&xin)[COLS])
+{
+    static_assert(ROWS <= PS || ROWS % PS == 0, "results with rows > 2 and odd: the reference's order depends on alignment");
+    double t[COLS];
+#pragma unroll
+    for (int k = 0; k < COLS; k++) t[k] = M[k * ROWS + i] * xin[k];
+    if constexpr (ROWS > 1 && ROWS % PS == 0) return seq_sum(t);
+    else if constexpr (ROWS == 1) return vec_sum(t);
+    else return novec_sum(t);
+}
+
+struct Params64
+{
+    int nx, nu, N, batch, bpad;
+    double rho, abs_pri_tol, abs_dua_tol;
+    int max_iter, check_termination, en_state_bound, en_input_bound;
+    double *arr[TINY_ARR_COUNT];
+    const double *xref, *xmin, *xmax, *umin, *umax; // [steps][dim][stride]; stride = bpad (per instance) or 1 (shared)
+    int xref_stride, xb_stride, ub_stride;
+    const double *mats; // Kinf | Pinf | Quu_inv | AmBKt | Adyn | Bdyn | Q, column-major
+    double *res;        // [4][bpad]
+    int *status, *iter, *n_unsolved;
+};
+
+template <int NX, int NU>
+__global__ __launch_bounds__(WAVE64) void admm_f64_kernel(const Params64 P)
+{
+    static_assert(!(NX >= 8 && NU >= 8), "both dims >= 8: Eigen switches to its GEMV kernel, not restated here");
+    constexpr int NMAT = NU * NX + NX * NX + NU * NU + NX * NX + NX * NX + NX * NU + NX;
+    __shared__ double mats[NMAT];
+    for (int e = threadIdx.x; e < NMAT; e += WAVE64) mats[e] = P.mats[e];
+    __syncthreads();
+    const double *K = mats, *Pinf = K + NU * NX, *Quu = Pinf + NX * NX, *Am = Quu + NU * NU, *A = Am + NX * NX, *Bm = A + NX * NX,
+                 *Q = Bm + NX * NU;
+
+    const int b = blockIdx.x * WAVE64 + threadIdx.x;
+    const bool valid = b < P.batch;
+    const int N = P.N;
+    const size_t bp = (size_t)P.bpad;
+    const double rho = P.rho;
+    auto at = [&](int id, int step, int row, int dim) -> double & { return P.arr[id][((size_t)step * dim + row) * bp + b]; };
+    auto in = [&](const double *base, int stride, int step, int row, int dim) {
+        return base[((size_t)step * dim + row) * (size_t)stride + (stride > 1 ? b : 0)];
+    };
+
+    if (P.max_iter <= 0) // tiny_solve only sets status and iter (admm.cpp:114-117,151)
+    {
+        if (valid)
+        {
+            P.status[b] = ST_UNSOLVED; P.iter[b] = 1;
+            atomicAdd(P.n_unsolved, 1);
+        }
+        return;
+    }
+    double x0[NX];
+#pragma unroll
+    for (int j = 0; j < NX; j++) x0[j] = valid ? at(TINY_ARR_X, 0, j, NX) : 0.0;
+    double r_ps = 0, r_pi = 0, r_ds = 0, r_di = 0;
+    if (valid)
+    {
+        r_ps = P.res[0 * bp + b]; r_pi = P.res[1 * bp + b]; r_ds = P.res[2 * bp + b]; r_di = P.res[3 * bp + b];
+    }
+    int st = ST_UNSOLVED, itn = 1; // admm.cpp:114-115
+    bool active = valid;
+    for (int it = 0; it < P.max_iter; ++it)
+    {
+        if (!__any(active)) break;
+        if (active)
+        {
+            itn = it + 1; // admm.cpp:120
+            // ---- forward_pass (:27-37) + update_slack (:45-61) + update_dual (:67-71) + update_linear_cost (:77-85) + residuals (:95-98) ----
+            double x[NX], pN[NX];
+#pragma unroll
+            for (int j = 0; j < NX; j++) x[j] = x0[j];
+            double pri_x = 0, dua_x = 0, pri_u = 0, dua_u = 0;
+            for (int i = 0; i < N; i++)
+            {
+                double u[NU], xn[NX];
+                if (i < N - 1)
+                {
+#pragma unroll
+                    for (int j = 0; j < NU; j++) u[j] = -row_dot<NU, NX>(K, j, x) - at(TINY_ARR_D, i, j, NU);           // :31
+#pragma unroll
+                    for (int j = 0; j < NX; j++) xn[j] = row_dot<NX, NX>(A, j, x) + row_dot<NX, NU>(Bm, j, u);           // :35
+#pragma unroll
+                    for (int j = 0; j < NU; j++)
+                    {
+                        const double y = at(TINY_ARR_Y, i, j, NU);
+                        double zn = u[j] + y;                                                                             // :47
+                        if (P.en_input_bound)                                                                             // :51-54
+                        {
+                            const double lo = in(P.umin, P.ub_stride, i, j, NU), hi = in(P.umax, P.ub_stride, i, j, NU);
+                            zn = (lo < zn) ? zn : lo;
+                            zn = (zn < hi) ? zn : hi;
+                        }
+                        const double yn = y + u[j] - zn;                                                                  // :69
+                        const double pu = fabs(u[j] - zn), du = fabs(at(TINY_ARR_Z, i, j, NU) - zn);                      // :97-98
+                        pri_u = (i == 0 && j == 0) ? pu : (pu > pri_u ? pu : pri_u);
+                        dua_u = (i == 0 && j == 0) ? du : (du > dua_u ? du : dua_u);
+                        at(TINY_ARR_U, i, j, NU) = u[j];
+                        at(TINY_ARR_ZNEW, i, j, NU) = zn;
+                        at(TINY_ARR_Y, i, j, NU) = yn;
+                        at(TINY_ARR_R, i, j, NU) = -rho * (zn - yn);                                                      // :80
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NX; j++)
+                {
+                    const double g = at(TINY_ARR_G, i, j, NX);
+                    double vn = x[j] + g;                                                                                 // :48
+                    if (P.en_state_bound)                                                                                 // :57-60
+                    {
+                        const double lo = in(P.xmin, P.xb_stride, i, j, NX), hi = in(P.xmax, P.xb_stride, i, j, NX);
+                        vn = (lo < vn) ? vn : lo;
+                        vn = (vn < hi) ? vn : hi;
+                    }
+                    const double gn = g + x[j] - vn;                                                                      // :70
+                    const double px = fabs(x[j] - vn), dx = fabs(at(TINY_ARR_V, i, j, NX) - vn);                          // :95-96
+                    pri_x = (i == 0 && j == 0) ? px : (px > pri_x ? px : pri_x);
+                    dua_x = (i == 0 && j == 0) ? dx : (dx > dua_x ? dx : dua_x);
+                    at(TINY_ARR_X, i, j, NX) = x[j];
+                    at(TINY_ARR_VNEW, i, j, NX) = vn;
+                    at(TINY_ARR_G, i, j, NX) = gn;
+                    double q = -(in(P.xref, P.xref_stride, i, j, NX) * Q[j]);                                             // :81
+                    q = q - rho * (vn - gn);                                                                              // :82
+                    at(TINY_ARR_Q, i, j, NX) = q;
+                    if (i == N - 1) pN[j] = rho * (vn - gn); // second half of :84, applied below
+                }
+                if (i < N - 1)
+                {
+#pragma unroll
+                    for (int j = 0; j < NX; j++) x[j] = xn[j];
+                }
+            }
+            {
+                // p.col(N-1) = -(Xref.col(N-1)^T * Pinf)  (:83), then -= rho * (vnew - g)  (:84)
+                double xr[NX];
+#pragma unroll
+                for (int k = 0; k < NX; k++) xr[k] = in(P.xref, P.xref_stride, N - 1, k, NX);
+#pragma unroll
+                for (int j = 0; j < NX; j++)
+                {
+                    double t[NX];
+#pragma unroll
+                    for (int k = 0; k < NX; k++) t[k] = xr[k] * Pinf[j * NX + k];
+                    const double pt = -vec_sum(t);
+                    pN[j] = pt - pN[j];
+                    at(TINY_ARR_P, N - 1, j, NX) = pN[j];
+                }
+            }
+            // ---- termination_condition (:91-109) ----
+            bool conv = false;
+            if ((it + 1) % P.check_termination == 0)
+            {
+                r_ps = pri_x; r_ds = dua_x * rho; r_pi = pri_u; r_di = dua_u * rho;
+                conv = (r_ps < P.abs_pri_tol) && (r_pi < P.abs_pri_tol) && (r_ds < P.abs_dua_tol) && (r_di < P.abs_dua_tol);
+            }
+            if (conv)
+            {
+                st = ST_SOLVED; // :136, returns before the v/z copy and the backward pass
+                active = false;
+            }
+            else
+            {
+                // ---- v = vnew, z = znew (:141-142) + backward_pass_grad (:15-22) ----
+#pragma unroll
+                for (int j = 0; j < NX; j++) at(TINY_ARR_V, N - 1, j, NX) = at(TINY_ARR_VNEW, N - 1, j, NX);
+                double pn[NX];
+#pragma unroll
+                for (int j = 0; j < NX; j++) pn[j] = pN[j];
+                for (int i = N - 2; i >= 0; i--)
+                {
+                    double r[NU], tmp[NU], dn[NU], pi[NX];
+#pragma unroll
+                    for (int j = 0; j < NU; j++)
+                    {
+                        at(TINY_ARR_Z, i, j, NU) = at(TINY_ARR_ZNEW, i, j, NU);
+                        r[j] = at(TINY_ARR_R, i, j, NU);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NU; j++) // Bdyn^T p_{i+1} + r_i: column j of Bdyn is contiguous -> vectorised reduction
+                    {
+                        double t[NX];
+#pragma unroll
+                        for (int k = 0; k < NX; k++) t[k] = Bm[j * NX + k] * pn[k];
+                        tmp[j] = vec_sum(t) + r[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < NU; j++) dn[j] = row_dot<NU, NU>(Quu, j, tmp);                                    // :19
+#pragma unroll
+                    for (int j = 0; j < NX; j++)
+                    {
+                        at(TINY_ARR_V, i, j, NX) = at(TINY_ARR_VNEW, i, j, NX);
+                        double t[NX], tk[NU];
+#pragma unroll
+                        for (int k = 0; k < NX; k++) t[k] = Am[k * NX + j] * pn[k];
+                        const double a = (NU == 1 && NX % PS == 0) ? seq_sum(t) : novec_sum(t);
+#pragma unroll
+                        for (int m = 0; m < NU; m++) tk[m] = K[j * NU + m] * r[m]; // Kinf^T r: column j of Kinf is contiguous
+                        pi[j] = at(TINY_ARR_Q, i, j, NX) + a - vec_sum(tk);                                               // :20
+                    }
+#pragma unroll
+                    for (int j = 0; j < NU; j++) at(TINY_ARR_D, i, j, NU) = dn[j];
+#pragma unroll
+                    for (int j = 0; j < NX; j++)
+                    {
+                        at(TINY_ARR_P, i, j, NX) = pi[j];
+                        pn[j] = pi[j];
+                    }
+                }
+            }
+        }
+    }
+    if (valid)
+    {
+        P.res[0 * bp + b] = r_ps; P.res[1 * bp + b] = r_pi; P.res[2 * bp + b] = r_ds; P.res[3 * bp + b] = r_di;
+        P.status[b] = st;
+        P.iter[b] = itn;
+        if (st != ST_SOLVED) atomicAdd(P.n_unsolved, 1);
+    }
+}
+
+// host layout [cnt][steps][dim] (cnt = 1: shared, stored once with stride 1)  <->  device [steps][dim][stride]
+__global__ void pack64_kernel(const double *__restrict__ src, double *__restrict__ dst, int nb, int steps, int dim, int stride, int step0, int nsteps)
+{
+    const long long total = (long long)nb * nsteps * dim;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x)
+    {
+        const int b = (int)(e % nb);
+        const long long t = e / nb;
+        const int row = (int)(t % dim), s = (int)(t / dim);
+        dst[((long long)(step0 + s) * dim + row) * stride + (stride > 1 ? b : 0)] = src[((long long)b * steps + step0 + s) * dim + row];
+    }
+}
+__global__ void unpack64_kernel(const double *__restrict__ src, double *__restrict__ dst, int nb, int steps, int dim, int stride)
+{
+    const long long total = (long long)nb * steps * dim;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x)
+    {
+        const int b = (int)(e % nb);
+        const long long t = e / nb;
+        const int row = (int)(t % dim), s = (int)(t / dim);
+        dst[((long long)b * steps + s) * dim + row] = src[((long long)s * dim + row) * stride + b];
+    }
+}
+
+thread_local std::string g_err64;
+int fail64(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err64 = buf;
+    return code;
+}
+#define HIP64(expr)                                                                                         \
+    do                                                                                                      \
+    {                                                                                                       \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return fail64(TINY_BATCH_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+#define CHECK64(c, ...) \
+    if (!(c)) return fail64(TINY_BATCH_EINVAL, __VA_ARGS__)
+
+bool xfam(int id) { return id == TINY_ARR_X || id == TINY_ARR_Q || id == TINY_ARR_P || id == TINY_ARR_V || id == TINY_ARR_VNEW || id == TINY_ARR_G; }
+int grid64(long long total)
+{
+    long long g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+} // namespace
+
+struct TinyBatch64
+{
+    int nx = 0, nu = 0, N = 0, batch = 0, bpad = 0, device = 0;
+    double *arr[TINY_ARR_COUNT] = {};
+    double *in[5] = {};        // xref, xmin, xmax, umin, umax
+    int in_stride[5] = {1, 1, 1, 1, 1};
+    bool in_set[5] = {};
+    double *mats = nullptr, *res = nullptr, *staging = nullptr;
+    int *status = nullptr, *iter = nullptr, *n_unsolved = nullptr;
+    std::vector<double> hm; // host copy of the packed matrices
+    bool have_cache = false, have_dyn = false, have_settings = false, mats_dirty = true;
+    double rho = 0, abs_pri_tol = 0, abs_dua_tol = 0;
+    int max_iter = 0, check_termination = 1, en_state_bound = 0, en_input_bound = 0;
+};
+
+namespace
+{
+size_t steps_of(const TinyBatch64 *tb, int id) { return xfam(id) ? tb->N : tb->N - 1; }
+int dim_of(const TinyBatch64 *tb, int id) { return xfam(id) ? tb->nx : tb->nu; }
+size_t mat_off(const TinyBatch64 *tb, int which) // Kinf, Pinf, Quu_inv, AmBKt, Adyn, Bdyn, Q
+{
+    const size_t nx = tb->nx, nu = tb->nu;
+    const size_t sz[7] = {nu * nx, nx * nx, nu * nu, nx * nx, nx * nx, nx * nu, nx};
+    size_t o = 0;
+    for (int k = 0; k < which; k++) o += sz[k];
+    return o;
+}
+int set_input(TinyBatch64 *tb, int which, const double *src, int shared)
+{
+    CHECK64(tb && src, "NULL argument");
+    HIP64(hipSetDevice(tb->device));
+    const int dim = which < 3 ? tb->nx : tb->nu, steps = which < 3 ? tb->N : tb->N - 1;
+    const int stride = shared ? 1 : tb->bpad, nb = shared ? 1 : tb->batch;
+    if (tb->in[which] && tb->in_stride[which] != stride) { (void)hipFree(tb->in[which]); tb->in[which] = nullptr; }
+    if (!tb->in[which])
+    {
+        HIP64(hipMalloc((void **)&tb->in[which], (size_t)steps * dim * stride * sizeof(double)));
+        HIP64(hipMemset(tb->in[which], 0, (size_t)steps * dim * stride * sizeof(double)));
+    }
+    HIP64(hipMemcpy(tb->staging, src, (size_t)nb * steps * dim * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pack64_kernel, dim3(grid64((long long)nb * steps * dim)), dim3(256), 0, 0, tb->staging, tb->in[which], nb, steps, dim, stride, 0, steps);
+    HIP64(hipGetLastError());
+    HIP64(hipDeviceSynchronize());
+    tb->in_stride[which] = stride;
+    tb->in_set[which] = true;
+    return 0;
+}
+} // namespace
+
+extern "C"
+{
+
+int tiny_batch64_create(TinyBatch64 **out, int nx, int nu, int N, int batch, int device)
+{
+    CHECK64(out, "NULL out pointer");
+    *out = nullptr;
+    CHECK64(nx >= 1 && nu >= 1 && N >= 2 && batch >= 1, "need nx>=1, nu>=1, N>=2, batch>=1 (got %d,%d,%d,%d)", nx, nu, N, batch);
+    if (!((nx == 12 && nu == 4) || (nx == 4 && nu == 1) || (nx == 8 && nu == 4)))
+        return fail64(TINY_BATCH_EUNSUPPORTED, "no fp64 kernel instantiation for nx=%d nu=%d (compiled: (12,4), (4,1), (8,4))", nx, nu);
+    int ndev = 0;
+    HIP64(hipGetDeviceCount(&ndev));
+    CHECK64(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
+    HIP64(hipSetDevice(device));
+    TinyBatch64 *tb = new TinyBatch64();
+    tb->nx = nx; tb->nu = nu; tb->N = N; tb->batch = batch; tb->device = device;
+    tb->bpad = (batch + WAVE64 - 1) / WAVE64 * WAVE64;
+    auto zalloc = [&](void **p, size_t bytes) {
+        if (hipMalloc(p, bytes) != hipSuccess) return false;
+        return hipMemset(*p, 0, bytes) == hipSuccess;
+    };
+    bool ok = true;
+    for (int id = 0; id < TINY_ARR_COUNT && ok; id++)
+        ok = zalloc((void **)&tb->arr[id], steps_of(tb, id) * dim_of(tb, id) * tb->bpad * sizeof(double));
+    ok = ok && zalloc((void **)&tb->res, 4 * (size_t)tb->bpad * sizeof(double)) && zalloc((void **)&tb->status, tb->bpad * sizeof(int)) &&
+         zalloc((void **)&tb->iter, tb->bpad * sizeof(int)) && zalloc((void **)&tb->n_unsolved, sizeof(int)) &&
+         zalloc((void **)&tb->staging, (size_t)batch * N * (nx > nu ? nx : nu) * sizeof(double)) &&
+         zalloc((void **)&tb->mats, (mat_off(tb, 6) + nx) * sizeof(double));
+    // inputs that were never set read as zero (the reference's zero-initialised members)
+    for (int w = 0; w < 5 && ok; w++)
+        ok = zalloc((void **)&tb->in[w], (size_t)(w < 3 ? N * nx : (N - 1) * nu) * sizeof(double));
+    if (!ok || hipDeviceSynchronize() != hipSuccess)
+    {
+        tiny_batch64_destroy(tb);
+        return fail64(TINY_BATCH_EHIP, "device allocation failed");
+    }
+    tb->hm.assign(mat_off(tb, 6) + nx, 0.0);
+    *out = tb;
+    return 0;
+}
+
+void tiny_batch64_destroy(TinyBatch64 *tb)
+{
+    if (!tb) return;
+    (void)hipSetDevice(tb->device);
+    for (int id = 0; id < TINY_ARR_COUNT; id++) (void)hipFree(tb->arr[id]);
+    for (int w = 0; w < 5; w++) (void)hipFree(tb->in[w]);
+    (void)hipFree(tb->mats); (void)hipFree(tb->res); (void)hipFree(tb->staging);
+    (void)hipFree(tb->status); (void)hipFree(tb->iter); (void)hipFree(tb->n_unsolved);
+    delete tb;
+}
+
+int tiny_batch64_set_cache(TinyBatch64 *tb, double rho, const double *Kinf, const double *Pinf, const double *Quu_inv, const double *AmBKt)
+{
+    CHECK64(tb && Kinf && Pinf && Quu_inv && AmBKt, "NULL argument");
+    const size_t nx = tb->nx, nu = tb->nu;
+    tb->rho = rho;
+    std::copy(Kinf, Kinf + nu * nx, tb->hm.begin() + mat_off(tb, 0));
+    std::copy(Pinf, Pinf + nx * nx, tb->hm.begin() + mat_off(tb, 1));
+    std::copy(Quu_inv, Quu_inv + nu * nu, tb->hm.begin() + mat_off(tb, 2));
+    std::copy(AmBKt, AmBKt + nx * nx, tb->hm.begin() + mat_off(tb, 3));
+    tb->have_cache = true; tb->mats_dirty = true;
+    return 0;
+}
+
+int tiny_batch64_set_dynamics(TinyBatch64 *tb, const double *Adyn, const double *Bdyn, const double *Q)
+{
+    CHECK64(tb && Adyn && Bdyn && Q, "NULL argument");
+    const size_t nx = tb->nx, nu = tb->nu;
+    std::copy(Adyn, Adyn + nx * nx, tb->hm.begin() + mat_off(tb, 4));
+    std::copy(Bdyn, Bdyn + nx * nu, tb->hm.begin() + mat_off(tb, 5));
+    std::copy(Q, Q + nx, tb->hm.begin() + mat_off(tb, 6));
+    tb->have_dyn = true; tb->mats_dirty = true;
+    return 0;
+}
+
+int tiny_batch64_set_settings(TinyBatch64 *tb, double abs_pri_tol, double abs_dua_tol, int max_iter, int check_termination,
+                              int en_state_bound, int en_input_bound)
+{
+    CHECK64(tb, "NULL handle");
+    CHECK64(check_termination >= 1, "check_termination must be >= 1 (the reference computes iter %% check_termination, admm.cpp:93)");
+    tb->abs_pri_tol = abs_pri_tol; tb->abs_dua_tol = abs_dua_tol; tb->max_iter = max_iter; tb->check_termination = check_termination;
+    tb->en_state_bound = en_state_bound; tb->en_input_bound = en_input_bound;
+    tb->have_settings = true;
+    return 0;
+}
+
+int tiny_batch64_set_x0(TinyBatch64 *tb, const double *x0)
+{
+    CHECK64(tb && x0, "NULL argument");
+    HIP64(hipSetDevice(tb->device));
+    HIP64(hipMemcpy(tb->staging, x0, (size_t)tb->batch * tb->nx * sizeof(double), hipMemcpyHostToDevice));
+    // [B][1][nx] -> step 0 of x
+    hipLaunchKernelGGL(pack64_kernel, dim3(grid64((long long)tb->batch * tb->nx)), dim3(256), 0, 0, tb->staging, tb->arr[TINY_ARR_X], tb->batch, 1,
+                       tb->nx, tb->bpad, 0, 1);
+    HIP64(hipGetLastError());
+    HIP64(hipDeviceSynchronize());
+    return 0;
+}
+
+int tiny_batch64_set_xref(TinyBatch64 *tb, const double *xref, int shared) { return set_input(tb, 0, xref, shared); }
+int tiny_batch64_set_xmin(TinyBatch64 *tb, const double *v, int shared) { return set_input(tb, 1, v, shared); }
+int tiny_batch64_set_xmax(TinyBatch64 *tb, const double *v, int shared) { return set_input(tb, 2, v, shared); }
+int tiny_batch64_set_umin(TinyBatch64 *tb, const double *v, int shared) { return set_input(tb, 3, v, shared); }
+int tiny_batch64_set_umax(TinyBatch64 *tb, const double *v, int shared) { return set_input(tb, 4, v, shared); }
+
+int tiny_batch64_reset_dual_variables(TinyBatch64 *tb)
+{
+    CHECK64(tb, "NULL handle");
+    HIP64(hipSetDevice(tb->device));
+    HIP64(hipMemset(tb->arr[TINY_ARR_Y], 0, (size_t)(tb->N - 1) * tb->nu * tb->bpad * sizeof(double)));
+    HIP64(hipMemset(tb->arr[TINY_ARR_G], 0, (size_t)tb->N * tb->nx * tb->bpad * sizeof(double)));
+    return 0;
+}
+
+int tiny_batch64_solve(TinyBatch64 *tb)
+{
+    CHECK64(tb, "NULL handle");
+    if (!tb->have_cache || !tb->have_dyn || !tb->have_settings)
+        return fail64(TINY_BATCH_ENOTREADY, "tiny_batch64_solve: set_cache, set_dynamics and set_settings must be called first");
+    if (tb->in_stride[1] != tb->in_stride[2] || tb->in_stride[3] != tb->in_stride[4])
+        return fail64(TINY_BATCH_EINVAL, "min and max bounds must both be shared or both be per-instance");
+    HIP64(hipSetDevice(tb->device));
+    if (tb->mats_dirty)
+    {
+        HIP64(hipMemcpy(tb->mats, tb->hm.data(), tb->hm.size() * sizeof(double), hipMemcpyHostToDevice));
+        tb->mats_dirty = false;
+    }
+    Params64 P;
+    P.nx = tb->nx; P.nu = tb->nu; P.N = tb->N; P.batch = tb->batch; P.bpad = tb->bpad;
+    P.rho = tb->rho; P.abs_pri_tol = tb->abs_pri_tol; P.abs_dua_tol = tb->abs_dua_tol;
+    P.max_iter = tb->max_iter; P.check_termination = tb->check_termination;
+    P.en_state_bound = tb->en_state_bound; P.en_input_bound = tb->en_input_bound;
+    for (int id = 0; id < TINY_ARR_COUNT; id++) P.arr[id] = tb->arr[id];
+    P.xref = tb->in[0]; P.xmin = tb->in[1]; P.xmax = tb->in[2]; P.umin = tb->in[3]; P.umax = tb->in[4];
+    P.xref_stride = tb->in_stride[0]; P.xb_stride = tb->in_stride[1]; P.ub_stride = tb->in_stride[3];
+    P.mats = tb->mats; P.res = tb->res; P.status = tb->status; P.iter = tb->iter; P.n_unsolved = tb->n_unsolved;
+    HIP64(hipMemset(tb->n_unsolved, 0, sizeof(int)));
+    const int nblocks = tb->bpad / WAVE64;
+    if (tb->nx == 12 && tb->nu == 4) hipLaunchKernelGGL((admm_f64_kernel<12, 4>), dim3(nblocks), dim3(WAVE64), 0, 0, P);
+    else if (tb->nx == 4 && tb->nu == 1) hipLaunchKernelGGL((admm_f64_kernel<4, 1>), dim3(nblocks), dim3(WAVE64), 0, 0, P);
+    else hipLaunchKernelGGL((admm_f64_kernel<8, 4>), dim3(nblocks), dim3(WAVE64), 0, 0, P);
+    HIP64(hipGetLastError());
+    int n = 0;
+    HIP64(hipMemcpy(&n, tb->n_unsolved, sizeof(int), hipMemcpyDeviceToHost));
+    return n > 0 ? 1 : 0;
+}
+
+int tiny_batch64_set_array(TinyBatch64 *tb, int id, const double *src)
+{
+    CHECK64(tb && src, "NULL argument");
+    CHECK64(id >= 0 && id < TINY_ARR_COUNT, "bad array id %d", id);
+    HIP64(hipSetDevice(tb->device));
+    const int steps = (int)steps_of(tb, id), dim = dim_of(tb, id);
+    HIP64(hipMemcpy(tb->staging, src, (size_t)tb->batch * steps * dim * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pack64_kernel, dim3(grid64((long long)tb->batch * steps * dim)), dim3(256), 0, 0, tb->staging, tb->arr[id], tb->batch, steps, dim,
+                       tb->bpad, 0, steps);
+    HIP64(hipGetLastError());
+    HIP64(hipDeviceSynchronize());
+    return 0;
+}
+
+int tiny_batch64_get_array(TinyBatch64 *tb, int id, double *dst)
+{
+    CHECK64(tb && dst, "NULL argument");
+    CHECK64(id >= 0 && id < TINY_ARR_COUNT, "bad array id %d", id);
+    HIP64(hipSetDevice(tb->device));
+    const int steps = (int)steps_of(tb, id), dim = dim_of(tb, id);
+    hipLaunchKernelGGL(unpack64_kernel, dim3(grid64((long long)tb->batch * steps * dim)), dim3(256), 0, 0, tb->arr[id], tb->staging, tb->batch, steps, dim,
+                       tb->bpad);
+    HIP64(hipGetLastError());
+    HIP64(hipMemcpy(dst, tb->staging, (size_t)tb->batch * steps * dim * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tiny_batch64_get_status(TinyBatch64 *tb, int *iter, int *status, double *residuals)
+{
+    CHECK64(tb, "NULL handle");
+    HIP64(hipSetDevice(tb->device));
+    if (iter) HIP64(hipMemcpy(iter, tb->iter, (size_t)tb->batch * sizeof(int), hipMemcpyDeviceToHost));
+    if (status) HIP64(hipMemcpy(status, tb->status, (size_t)tb->batch * sizeof(int), hipMemcpyDeviceToHost));
+    if (residuals)
+    {
+        std::vector<double> tmp(4 * (size_t)tb->bpad);
+        HIP64(hipMemcpy(tmp.data(), tb->res, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int b = 0; b < tb->batch; b++)
+            for (int k = 0; k < 4; k++) residuals[4 * (size_t)b + k] = tmp[(size_t)k * tb->bpad + b];
+    }
+    return 0;
+}
+
+int tiny_batch64_set_status(TinyBatch64 *tb, const int *iter, const int *status, const double *residuals)
+{
+    CHECK64(tb, "NULL handle");
+    HIP64(hipSetDevice(tb->device));
+    if (iter) HIP64(hipMemcpy(tb->iter, iter, (size_t)tb->batch * sizeof(int), hipMemcpyHostToDevice));
+    if (status) HIP64(hipMemcpy(tb->status, status, (size_t)tb->batch * sizeof(int), hipMemcpyHostToDevice));
+    if (residuals)
+    {
+        std::vector<double> tmp(4 * (size_t)tb->bpad, 0.0);
+        for (int b = 0; b < tb->batch; b++)
+            for (int k = 0; k < 4; k++) tmp[(size_t)k * tb->bpad + b] = residuals[4 * (size_t)b + k];
+        HIP64(hipMemcpy(tb->res, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+const char *tiny_batch64_last_error(void) { return g_err64.c_str(); }
+
+} // extern "C"

@@ -83,6 +83,23 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
     for name, args in sig.items():
         fn = getattr(lib, name)
         fn.argtypes, fn.restype = args, C.c_int
+    # fp64 library (include/tinympc_batch64.h)
+    sig64 = {
+        "tiny_batch64_create": [C.POINTER(P), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
+        "tiny_batch64_set_cache": [P, C.c_double, D, D, D, D], "tiny_batch64_set_dynamics": [P, D, D, D],
+        "tiny_batch64_set_settings": [P, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int],
+        "tiny_batch64_set_x0": [P, D], "tiny_batch64_set_xref": [P, D, C.c_int],
+        "tiny_batch64_set_xmin": [P, D, C.c_int], "tiny_batch64_set_xmax": [P, D, C.c_int],
+        "tiny_batch64_set_umin": [P, D, C.c_int], "tiny_batch64_set_umax": [P, D, C.c_int],
+        "tiny_batch64_reset_dual_variables": [P], "tiny_batch64_solve": [P],
+        "tiny_batch64_set_array": [P, C.c_int, D], "tiny_batch64_get_array": [P, C.c_int, D],
+        "tiny_batch64_get_status": [P, I, I, D], "tiny_batch64_set_status": [P, I, I, D],
+    }
+    for name, args in sig64.items():
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = args, C.c_int
+    lib.tiny_batch64_destroy.argtypes, lib.tiny_batch64_destroy.restype = [P], None
+    lib.tiny_batch64_last_error.argtypes, lib.tiny_batch64_last_error.restype = [], C.c_char_p
     lib.tiny_batch_destroy.argtypes, lib.tiny_batch_destroy.restype = [P], None
     lib.tiny_batch_last_error.argtypes, lib.tiny_batch_last_error.restype = [], C.c_char_p
     lib.tiny_batch_kernel_name.argtypes, lib.tiny_batch_kernel_name.restype = [P], C.c_char_p
@@ -91,10 +108,10 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
 
 
 def exported_symbols():
-    """Names declared in include/tinympc_batch.h (used by the CPU-side ABI test)."""
+    """Names declared in include/tinympc_batch.h and include/tinympc_batch64.h (used by the CPU-side ABI test)."""
     import re
-    txt = (PKG.parent / "include" / "tinympc_batch.h").read_text()
-    return sorted(set(re.findall(r"\b(tiny_(?:batch_[a-z0-9_]+|riccati))\s*\(", txt)))
+    txt = (PKG.parent / "include" / "tinympc_batch.h").read_text() + (PKG.parent / "include" / "tinympc_batch64.h").read_text()
+    return sorted(set(re.findall(r"\b(tiny_(?:batch(?:64)?_[a-z0-9_]+|riccati))\s*\(", txt)))
 
 
 def _f32(a):
@@ -371,3 +388,104 @@ class TinyBatchSolver:
 
     def set_stream(self, stream_ptr: int):
         self._check(self.lib.tiny_batch_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+
+class TinyBatchSolver64:
+    """The same host mirror for `typedef double tinytype` (include/tinympc_batch64.h; the reference as shipped,
+    glob_opts.hpp:3): wrapper-style calls over a device-resident fp64 workspace, bitwise equal to the compiled reference."""
+
+    def __init__(self, prob: dict, batch: int, device: int = 0, settings: dict | None = None):
+        self.lib = load_library()
+        self.nx, self.nu, self.N, self.B = int(prob["nx"]), int(prob["nu"]), int(prob["N"]), int(batch)
+        self._h = C.c_void_p()
+        self._check(self.lib.tiny_batch64_create(C.byref(self._h), self.nx, self.nu, self.N, self.B, int(device)))
+        cm = lambda m: np.ascontiguousarray(np.asarray(m, np.float64).T).ravel()
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        k, p, qi, am = (cm(prob[n]) for n in ("Kinf", "Pinf", "Quu_inv", "AmBKt"))
+        self._check(self.lib.tiny_batch64_set_cache(self._h, float(prob["rho"]), dp(k), dp(p), dp(qi), dp(am)))
+        a, b, q = cm(prob["Adyn"]), cm(prob["Bdyn"]), np.ascontiguousarray(np.asarray(prob["Q"], np.float64).ravel())
+        self._check(self.lib.tiny_batch64_set_dynamics(self._h, dp(a), dp(b), dp(q)))
+        s = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1, en_state_bound=1, en_input_bound=1)
+        if settings:
+            s.update(settings)
+        self.set_settings(**s)
+
+    def _check(self, rc):
+        if rc < 0:
+            raise TinyBatchError(f"rc={rc}: {self.lib.tiny_batch64_last_error().decode()}")
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.tiny_batch64_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _dp(a):
+        return a.ctypes.data_as(C.POINTER(C.c_double))
+
+    def _xshape(self, name):
+        return (self.B, self.N, self.nx) if name in X_FAMILY else (self.B, self.N - 1, self.nu)
+
+    def set_settings(self, abs_pri_tol, abs_dua_tol, max_iter, check_termination, en_state_bound, en_input_bound):
+        self.settings = dict(abs_pri_tol=abs_pri_tol, abs_dua_tol=abs_dua_tol, max_iter=max_iter, check_termination=check_termination,
+                             en_state_bound=en_state_bound, en_input_bound=en_input_bound)
+        self._check(self.lib.tiny_batch64_set_settings(self._h, abs_pri_tol, abs_dua_tol, max_iter, check_termination, en_state_bound, en_input_bound))
+
+    def set_x0(self, x0):
+        a = np.ascontiguousarray(x0, np.float64); assert a.shape == (self.B, self.nx), a.shape
+        self._check(self.lib.tiny_batch64_set_x0(self._h, self._dp(a)))
+
+    def _set_steps(self, fn, arr, steps, dim):
+        a = np.ascontiguousarray(arr, np.float64)
+        shared = 1 if a.shape == (steps, dim) else 0
+        assert shared or a.shape == (self.B, steps, dim), a.shape
+        self._check(fn(self._h, self._dp(a), shared))
+
+    def set_xref(self, xref): self._set_steps(self.lib.tiny_batch64_set_xref, xref, self.N, self.nx)
+
+    def set_bounds(self, x_min, x_max, u_min, u_max):
+        self._set_steps(self.lib.tiny_batch64_set_xmin, x_min, self.N, self.nx)
+        self._set_steps(self.lib.tiny_batch64_set_xmax, x_max, self.N, self.nx)
+        self._set_steps(self.lib.tiny_batch64_set_umin, u_min, self.N - 1, self.nu)
+        self._set_steps(self.lib.tiny_batch64_set_umax, u_max, self.N - 1, self.nu)
+
+    def reset_dual_variables(self): self._check(self.lib.tiny_batch64_reset_dual_variables(self._h))
+
+    def solve(self) -> int: return self._check(self.lib.tiny_batch64_solve(self._h))
+
+    def get_array(self, name):
+        out = np.empty(self._xshape(name), np.float64)
+        self._check(self.lib.tiny_batch64_get_array(self._h, ARRAY_IDS[name], self._dp(out)))
+        return out
+
+    def set_array(self, name, arr):
+        a = np.ascontiguousarray(arr, np.float64); assert a.shape == self._xshape(name), (name, a.shape)
+        self._check(self.lib.tiny_batch64_set_array(self._h, ARRAY_IDS[name], self._dp(a)))
+
+    def get_u(self): return self.get_array("u")
+
+    def get_status(self):
+        it = np.zeros(self.B, np.int32); st = np.zeros(self.B, np.int32); res = np.zeros((self.B, 4), np.float64)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+        self._check(self.lib.tiny_batch64_get_status(self._h, ip(it), ip(st), self._dp(res)))
+        return it, st, res
+
+    def get_state(self) -> dict:
+        st = {k: self.get_array(k) for k in ARRAY_IDS}
+        st["iter"], st["status"], st["residuals"] = self.get_status()
+        return st
+
+    def set_state(self, st: dict):
+        for k in ARRAY_IDS:
+            if k in st:
+                self.set_array(k, st[k])
+        ip = lambda a: np.ascontiguousarray(a, np.int32)
+        it, sta, res = ip(st["iter"]), ip(st["status"]), np.ascontiguousarray(st["residuals"], np.float64)
+        self._check(self.lib.tiny_batch64_set_status(self._h, it.ctypes.data_as(C.POINTER(C.c_int)), sta.ctypes.data_as(C.POINTER(C.c_int)), self._dp(res)))

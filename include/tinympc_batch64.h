@@ -1,0 +1,66 @@
+/*
+ * tinympc_batch64.h — C-ABI of the batched TinyMPC ADMM solver for `typedef double tinytype`.
+ *
+ * The reference ships with tinytype = double (src/tinympc/glob_opts.hpp:3: NSTATES 12, NINPUTS 4, NHORIZON 10 as checked
+ * in); its code generator switches to float for microcontrollers (codegen.cpp:152).  tinympc_batch.h is the float
+ * library; this header is the same drop-in boundary — tiny_solve() (src/tinympc/admm.cpp:111-152) over a batch of
+ * independent instances of one problem class — in double, for callers that run the reference as shipped.
+ *
+ * Same conventions as tinympc_batch.h: plain C, host pointers, column-major matrices (types.hpp:13-21), batched arrays
+ * in the array-of-reference-instances layout ([B][N][nx] / [B][N-1][nu]), device-resident workspace that persists
+ * between solves (the warm start), every function returns 0 or a negative TinyBatchError (tinympc_batch.h),
+ * tiny_batch_last_error() holds the message.  Arithmetic: every product and sum separately rounded in the order of the
+ * reference's SSE2 Eigen build with 2-double packets; results are BITWISE equal to the compiled reference (all twelve
+ * work arrays, the residuals, status, iter).
+ *
+ * Scope: tiny_solve and the wrapper-style accessors.  Problem classes with a compiled instantiation: (nx, nu) =
+ * (12, 4), (4, 1), (8, 4), any horizon N.  One thread per instance, state in HBM (fp64 halves the register budget of the
+ * state-on-chip kernels; the double path is the reference's desktop configuration, not the throughput path).
+ */
+#ifndef TINYMPC_BATCH64_H
+#define TINYMPC_BATCH64_H
+
+#include "tinympc_batch.h"
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+    typedef struct TinyBatch64 TinyBatch64;
+
+    /* Replaces the caller-owned TinyCache/TinyWorkspace/TinySettings/TinySolver (types.hpp:26-107) with tinytype = double
+     * (glob_opts.hpp:3).  The workspace starts all zero (quadrotor_hovering.cpp:49-71). */
+    const char *tiny_batch64_last_error(void);
+    int tiny_batch64_create(TinyBatch64 **out, int nx, int nu, int N, int batch, int device);
+    void tiny_batch64_destroy(TinyBatch64 *tb);
+
+    /* TinyCache (types.hpp:26-34) and the per-problem members of TinyWorkspace (types.hpp:82-85), column-major doubles. */
+    int tiny_batch64_set_cache(TinyBatch64 *tb, double rho, const double *Kinf, const double *Pinf, const double *Quu_inv, const double *AmBKt);
+    int tiny_batch64_set_dynamics(TinyBatch64 *tb, const double *Adyn, const double *Bdyn, const double *Q);
+    /* TinySettings (types.hpp:39-47) */
+    int tiny_batch64_set_settings(TinyBatch64 *tb, double abs_pri_tol, double abs_dua_tol, int max_iter, int check_termination,
+                                  int en_state_bound, int en_input_bound);
+
+    /* wrapper twins (tiny_wrapper.hpp:14-23), batched, double: `shared` != 0 means one [N][nx] / [N-1][nu] array for the batch */
+    int tiny_batch64_set_x0(TinyBatch64 *tb, const double *x0);                 /* [B][nx] -> x.col(0) */
+    int tiny_batch64_set_xref(TinyBatch64 *tb, const double *xref, int shared); /* [B or 1][N][nx] */
+    int tiny_batch64_set_xmin(TinyBatch64 *tb, const double *v, int shared);
+    int tiny_batch64_set_xmax(TinyBatch64 *tb, const double *v, int shared);
+    int tiny_batch64_set_umin(TinyBatch64 *tb, const double *v, int shared);
+    int tiny_batch64_set_umax(TinyBatch64 *tb, const double *v, int shared);
+    int tiny_batch64_reset_dual_variables(TinyBatch64 *tb);                     /* y = 0, g = 0 (tiny_wrapper.cpp:131) */
+    /* tiny_solve() for every instance (admm.cpp:111-152): 0 = all converged, 1 = some hit max_iter, < 0 = error */
+    int tiny_batch64_solve(TinyBatch64 *tb);
+
+    /* whole workspace, ids of TinyBatchArray */
+    int tiny_batch64_set_array(TinyBatch64 *tb, int id, const double *src);
+    int tiny_batch64_get_array(TinyBatch64 *tb, int id, double *dst);
+    /* work->iter, work->status and the four residual fields (pri_state, pri_input, dua_state, dua_input); NULL = skip */
+    int tiny_batch64_get_status(TinyBatch64 *tb, int *iter, int *status, double *residuals);
+    int tiny_batch64_set_status(TinyBatch64 *tb, const int *iter, const int *status, const double *residuals);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1769,3 +1769,87 @@ def test_per_instance_bounds_stay_on_the_register_resident_kernel_and_cost_littl
     print("kernel ms, shared vs per-instance bounds:", res["shared"][0], res["per_instance"][0])
     assert np.array_equal(res["shared"][1], res["per_instance"][1]) and np.array_equal(res["shared"][2], res["per_instance"][2])
     assert res["per_instance"][0] <= 1.25 * res["shared"][0], (res["shared"][0], res["per_instance"][0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tinytype = double (the reference as shipped, glob_opts.hpp:3): include/tinympc_batch64.h
+# ---------------------------------------------------------------------------------------------------------------------
+def test_fp64_as_shipped_hovering_loop_and_golden_vectors(tinympc, oracle_mod):
+    """The reference exactly as checked in — typedef double tinytype, NSTATES 12, NINPUTS 4, NHORIZON 10 (glob_opts.hpp:3-7),
+    examples/quadrotor_hovering.cpp — through the fp64 library: the recorded solves (k = 0 and k = 69) reproduce all twelve
+    work arrays, residuals, status and iter of the compiled reference bit for bit, and the whole 70-step closed loop reproduces
+    its controls and iteration counts (SURVEY.md §4 KATs: 1269 iterations, u0 = 0.488778532 ...)."""
+    O = oracle_mod
+    meta, prob, solves, z = load_fixture("quad_hover_f64_N10")
+    assert meta["dtype"] == "float64" and prob["N"] == 10
+    bnds = bounds_of(prob, np.float64)
+    for s in solves:
+        sol = tinympc.TinyBatchSolver64(prob, 1, settings=s["settings"])
+        sol.set_bounds(*bnds); sol.set_xref(s["xref"])
+        sol.set_state(s["pre"])
+        rc = sol.solve()
+        assert rc == (1 if s["rc"] else 0)
+        assert_bitwise(sol.get_state(), s["post"], f"fp64 golden solve k={s['k']}")
+        sol.close()
+    sol = tinympc.TinyBatchSolver64(prob, 1, settings=solves[0]["settings"])
+    sol.set_bounds(*bnds); sol.set_xref(solves[0]["xref"])
+    sol.set_state(solves[0]["pre"])
+    orc = O.Oracle(prob, np.float64)
+    x0 = solves[0]["pre"]["x"][:, 0].copy()
+    iters, u0s = [], []
+    for k in range(70):
+        sol.set_x0(x0)                       # hovering.cpp:95
+        sol.reset_dual_variables()           # :100-101
+        sol.solve()                          # :104
+        u0 = sol.get_u()[:, 0]
+        iters.append(int(sol.get_status()[0][0])); u0s.append(u0[0].copy())
+        x0 = orc.plant_step(x0, u0)          # :110-111 in the examples' own order (pinned in tests/test_oracle.py)
+    assert np.array_equal(np.array(iters), z["trace_iter"]) and np.array_equal(np.array(u0s), z["trace_u0"])
+    assert sum(iters) == 1269 and iters[0] == 100 and iters[69] == 2
+    np.testing.assert_allclose(u0s[0], [0.488778532, 0.478938215, 0.542743696, 0.551056731], rtol=0, atol=5e-10)
+    sol.close()
+
+
+@pytest.mark.parametrize("nx,nu,N", [(12, 4, 30), (12, 4, 10), (4, 1, 10), (8, 4, 9)])
+def test_fp64_vs_oracle(tinympc, oracle_mod, nx, nu, N):
+    """The fp64 library against the fp64 oracle (== the compiled reference's fp64 builds, tests/test_oracle.py) on random
+    warm states with zeros and negative zeros: ragged batches, warm-started chain with dual resets, sparse termination
+    checks, max_iter 0 / 1, bounds off, per-instance bounds and references.  Bitwise, signs of zeros included."""
+    O, pr = oracle_mod, tinympc.problems
+    if (nx, nu) == (12, 4):
+        prob = pr.quadrotor(20, N)
+    elif (nx, nu) == (4, 1):
+        prob = pr.cartpole(N, riccati=O.riccati)
+    else:
+        prob = pr.random_system(nx, nu, N, seed=nx * 100 + nu, riccati=O.riccati)
+    for B, settings, per_inst in ((1, {}, False), (63, dict(max_iter=30, check_termination=3), True), (130, dict(max_iter=1), False),
+                                  (65, dict(max_iter=0), False), (200, dict(max_iter=25, en_state_bound=0, en_input_bound=0), True)):
+        settings = dict(O.DEFAULT_SETTINGS, **settings)
+        rng = np.random.default_rng(B + nx)
+        st = O.new_state(B, nx, nu, N, np.float64)
+        for k in STATE_ORDER:
+            st[k][:] = rng.standard_normal(st[k].shape) * 0.3
+        for k in ("x", "d", "v", "z", "g", "y"):
+            st[k][rng.random(st[k].shape) < 0.1] = 0.0
+            st[k][rng.random(st[k].shape) < 0.1] = -0.0
+        st["residuals"][:] = rng.random((B, 4)); st["iter"][:] = 3; st["status"][:] = 11
+        shared = pr.bounds_arrays(prob, np.float64)
+        if per_inst:
+            bnds = tuple(a[None] * rng.uniform(0.1, 1.0, size=(B,) + a.shape) for a in shared)
+            xref = rng.standard_normal((B, N, nx)) * 0.2
+        else:
+            bnds, xref = shared, rng.standard_normal((N, nx)) * 0.2
+        sol = tinympc.TinyBatchSolver64(prob, B, settings=settings)
+        sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_state(st)
+        orc = O.Oracle(prob, np.float64, settings)
+        for k in range(3):
+            if k:
+                st["y"][:] = 0; st["g"][:] = 0
+                sol.reset_dual_variables()
+            rc_ref = orc.solve(st, *bnds, xref, nthreads=8)
+            rc = sol.solve()
+            assert rc == (1 if rc_ref else 0)
+            assert_bitwise(sol.get_state(), st, f"fp64 ({nx},{nu},{N}) B={B} {settings} per_inst={per_inst} k={k}")
+        sol.close()
+    with pytest.raises(tinympc.TinyBatchError):
+        tinympc.TinyBatchSolver64(dict(prob, nx=5), 4)
