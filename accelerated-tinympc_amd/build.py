@@ -16,9 +16,9 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libtinympc_hip.so"
 WRAPPER_LIB = PKG / "lib" / "libtinympc_wrapper.so"  # same-name twin of the reference's generated wrapper library
-SOURCES = ["tinympc_batch.hip", "tinympc_batch64.hip", "admm_stream.hip", "admm_rowlane.hip", "admm_rowloop.hip", "admm_quadlane.hip", "admm_tile16.hip", "admm_wave.hip", "admm_steps.hip", "dispatch_order.hip", "riccati.cpp"]
+SOURCES = ["tinympc_batch.hip", "tinympc_batch64.hip", "admm_stream.hip", "admm_rowlane.hip", "admm_rowloop.hip", "admm_quadlane.hip", "admm_tile16.hip", "admm_wave.hip", "admm_waveres.hip", "admm_steps.hip", "dispatch_order.hip", "riccati.cpp"]
 WRAPPER_SRCS = [CSRC / "wrapper_compat.cpp", CSRC / "admm_compat.cpp"]
-HEADERS = [CSRC / "tinympc_internal.h", CSRC / "rowlane_math.h", CSRC / "tile_math.h", CSRC / "dpp_ops_gen.h", PKG.parent / "include" / "tinympc_batch.h", PKG.parent / "include" / "tinympc_batch64.h"]
+HEADERS = [CSRC / "tinympc_internal.h", CSRC / "rowlane_math.h", CSRC / "tile_math.h", CSRC / "wave_math.h", CSRC / "dpp_ops_gen.h", PKG.parent / "include" / "tinympc_batch.h", PKG.parent / "include" / "tinympc_batch64.h"]
 # -ffp-contract=off : exact arithmetic must not fuse a*b+c; the fast paths call fma explicitly
 # -fno-slp-vectorize: hipcc otherwise pairs scalar fp32 adds into v_pk_add_f32 (+ v_mov to build the pairs), which on
 #                     gfx950 is slower than two plain v_add_f32 (measured, tools/micro/*.hip)

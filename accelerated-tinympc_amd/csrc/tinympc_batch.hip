@@ -236,6 +236,7 @@ struct TinyBatch
     int rw = 16; // lanes per instance-step of the ROW layout
     bool row_dims_ok = false, tile_dims_ok = false, rowmath_ok = false, rowloop_ok = false, wave_ok = false, quad_ok = false;
     bool tile16_ok = false; // admm_tile16.hip has an instantiation for (nx, nu, N)
+    bool waveres_ok = false; // admm_waveres.hip serves (nx, nu, N): wave class with N <= 50
     int *conv_dev = nullptr; // [batch] result of termination_condition
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr; // created by tiny_batch_group_solve / mpc_run for handles left on the null stream
@@ -738,7 +739,8 @@ int resolve_variant(TinyBatch *tb, int *out)
 // HBM (rowstream).  tiny_batch_set_row_kernel() can force one of them.
 int row_family(const TinyBatch *tb)
 {
-    if (tb->wave_ok) return 3; // one wavefront per instance, state in HBM (admm_wave.hip)
+    // one wavefront per instance: state on chip where the horizon fits (admm_waveres.hip, 6), else streamed through HBM (admm_wave.hip, 3)
+    if (tb->wave_ok) return (tb->waveres_ok && tb->row_family_forced != 3) ? 6 : 3;
     // per-instance bounds: the unrolled register-resident kernel reads them from the [B][N][16] table (fp32 storage), the
     // streaming row kernel serves every other case; the rolled-loop and quad kernels stage one shared table in LDS
     if (!bounds_all_shared(tb))
@@ -766,6 +768,7 @@ void update_kname(TinyBatch *tb)
     else if (row_family(tb) == 0) snprintf(nm, sizeof nm, "rowlane<%d,%d,%d,%s%s>", tb->nx, tb->nu, tb->N, ar, sto);
     else if (row_family(tb) == 1) snprintf(nm, sizeof nm, "rowloop<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
     else if (row_family(tb) == 3) snprintf(nm, sizeof nm, "wavestream<%d,%d,%s>", tb->nx, tb->nu, ar);
+    else if (row_family(tb) == 6) snprintf(nm, sizeof nm, "waveres<%d,%d,%s>", tb->nx, tb->nu, ar);
     else if (row_family(tb) == 4) snprintf(nm, sizeof nm, "quadlane<%d,%d,%d,%s%s>", tb->nx, tb->nu, tb->N, ar, sto);
     else if (row_family(tb) == 5) snprintf(nm, sizeof nm, "tile16<%d,%d,%d,%s>", tb->nx, tb->nu, tb->N, ar);
     else snprintf(nm, sizeof nm, "rowstream<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
@@ -928,6 +931,7 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
             : fam == 3 ? launch_admm_wavestream(tb->nx, tb->nu, P, tb->stream)
             : fam == 4 ? launch_admm_quadlane(tb->N, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
             : fam == 5 ? launch_admm_tile16(tb->N, v == VAR_ROW_EXACT, P, tb->stream)
+            : fam == 6 ? launch_admm_waveres(tb->nx, tb->nu, P, tb->stream)
                        : launch_admm_rowstream(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream);
     }
     if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -1007,6 +1011,7 @@ int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int dev
     tb->wave_ok = wave_ok;
     tb->quad_ok = tb->rowmath_ok && quadlane_supported(nx, nu, N);
     tb->tile16_ok = tb->rowmath_ok && tile16_supported(nx, nu, N);
+    tb->waveres_ok = wave_ok && waveres_supported(nx, nu, N);
     tb->rw = wave_ok ? 64 : 16;
     tb->xfam_floats = (size_t)tb->ntiles * N * WAVE * nxc;
     tb->ufam_floats = (size_t)tb->ntiles * (N - 1) * WAVE * nuc;
@@ -1559,13 +1564,13 @@ const char *tiny_batch_kernel_name(TinyBatch *tb)
 int tiny_batch_set_row_kernel(TinyBatch *tb, int family)
 {
     CHECK_TB(tb);
-    if (family < 0 || family > 5)
-        return fail(TINY_BATCH_EINVAL, "row kernel must be 0 (auto), 1 (rowlane), 2 (rowloop), 3 (rowstream), 4 (quadlane) or 5 (tile16)");
+    if (family < 0 || family > 7)
+        return fail(TINY_BATCH_EINVAL, "row kernel must be 0 (auto), 1 (rowlane), 2 (rowloop), 3 (rowstream), 4 (quadlane), 5 (tile16), 6 (wavestream) or 7 (waveres)");
     const bool ok = family == 0 || (family == 1 && tb->row_dims_ok) || (family == 2 && tb->rowloop_ok) || (family == 3 && tb->rowmath_ok) ||
-                    (family == 4 && tb->quad_ok) || (family == 5 && tb->tile16_ok);
+                    (family == 4 && tb->quad_ok) || (family == 5 && tb->tile16_ok) || (family == 6 && tb->wave_ok) || (family == 7 && tb->waveres_ok);
     if (!ok)
         return fail(TINY_BATCH_EUNSUPPORTED, "row kernel %d has no instantiation for nx=%d nu=%d N=%d", family, tb->nx, tb->nu, tb->N);
-    static const int kFam[6] = {-1, 0, 1, 2, 4, 5};
+    static const int kFam[8] = {-1, 0, 1, 2, 4, 5, 3, 6};
     tb->row_family_forced = kFam[family];
     invalidate_graph(tb);
     return 0;

@@ -142,6 +142,9 @@ hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t
 #define TINY_FOR_EACH_WAVEDIMS(X) X(32, 16) X(16, 8) X(16, 4)
 bool wavedims_supported(int nx, int nu);
 hipError_t launch_admm_wavestream(int nx, int nu, const RowParams &P, hipStream_t stream);
+// the same classes with the loop-carried state on chip (admm_waveres.hip): N <= 50
+bool waveres_supported(int nx, int nu, int N);
+hipError_t launch_admm_waveres(int nx, int nu, const RowParams &P, hipStream_t stream);
 
 hipError_t launch_admm_stream(int nxc, int nuc, const SolveParams &P, hipStream_t stream);
 

@@ -132,7 +132,8 @@ while time.time() < t_end:
             else:
                 same = np.array_equal(g_, r_)
             if not same:
-                print(f"MISMATCH round {rounds} h16={h16} {kind} N={N} B={B} kernel {sol.kernel_name()} settings {settings} xref mode {mode} solve {k}: {name}")
+                print(f"MISMATCH round {rounds} h16={h16} {kind} N={N} B={B} kernel {sol.kernel_name()} settings {settings} xref mode {mode} solve {k}: {name}"
+                      f" | per-instance bounds {bnds_raw[0].ndim == 3}, row kernel family {fam}, caller order {d_order is not None}, optional terms {opt}")
                 bad = np.argwhere(~((got[name] == st[name]) & (np.signbit(got[name]) == np.signbit(st[name]))))
                 for idx in bad[:6]:
                     idx = tuple(idx)

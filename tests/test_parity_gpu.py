@@ -253,9 +253,11 @@ def test_settings_variants_vs_oracle(tinympc, oracle_mod, variant):
         orc = O.Oracle(prob, np.float32, settings)
         sol = make_solver(tinympc, prob, B, settings, xref, variant, bnds)
         if bnds[0].ndim == 3 and variant != "stream":
-            # per-instance bounds: the register-resident kernels stage ONE bounds table in LDS, so every row variant runs
-            # on the streaming row kernel, which reads the bounds per instance (same arithmetic: still bitwise when exact)
-            assert sol.kernel_name().startswith("rowstream"), sol.kernel_name()
+            # per-instance bounds: the unrolled register-resident kernel reads them per lane-step from the [B][N][16] table;
+            # the rolled-loop kernel stages ONE table in LDS, so a handle forced onto it runs on the streaming row kernel
+            # instead (same arithmetic either way: still bitwise when exact)
+            want = "rowlane" if VARIANTS[variant][2] in (0, 1) else "rowstream"
+            assert sol.kernel_name().startswith(want), (variant, sol.kernel_name())
         st = O.new_state(B, 12, 4, 30)
         st["x"][:, 0] = x0
         st["residuals"][:] = rng.uniform(0, 1, size=(B, 4)).astype(np.float32)  # residual fields are live-in
@@ -921,9 +923,11 @@ def test_device_pointer_io_equals_host_io(tinympc):
     sol.close(); ref.close()
 
 
+@pytest.mark.parametrize("wave_kernel", ["wavestream", "waveres"])
 @pytest.mark.parametrize("B", [1, 3, 66])
-def test_wave_kernel_vs_oracle(tinympc, oracle_mod, B):
-    """nx = 32, nu = 16, N = 50 (BASELINE.json configs[3]) on the wave-per-instance exact kernel: bitwise equal to the
+def test_wave_kernel_vs_oracle(tinympc, oracle_mod, B, wave_kernel):
+    """nx = 32, nu = 16, N = 50 (BASELINE.json configs[3]) on the two wave-per-instance exact kernels (state streamed through
+    HBM / state in registers and LDS, the default for N <= 50): bitwise equal to the
     oracle (== the compiled reference for this class, tests/test_oracle.py) over a warm-started chain, with early exit,
     sparse termination checks, one iteration, bounds disabled and a random time-varying reference."""
     O, pr = oracle_mod, tinympc.problems
@@ -937,7 +941,9 @@ def test_wave_kernel_vs_oracle(tinympc, oracle_mod, B):
                      dict(max_iter=12, en_state_bound=0, en_input_bound=0), dict(max_iter=0)):
         settings = dict(O.DEFAULT_SETTINGS, **settings)
         sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
-        assert sol.kernel_name() == "wavestream<32,16,exact>", sol.kernel_name()
+        assert sol.kernel_name() == "waveres<32,16,exact>", sol.kernel_name()   # the automatic choice
+        sol.set_row_kernel(6 if wave_kernel == "wavestream" else 7)
+        assert sol.kernel_name() == f"{wave_kernel}<32,16,exact>", sol.kernel_name()
         sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
         orc = O.Oracle(prob, np.float32, settings)
         st = O.new_state(B, nx, nu, N); st["x"][:, 0] = x0
@@ -1127,7 +1133,7 @@ def test_kernel_selection_and_option_errors(tinympc):
         q40.set_row_kernel(2)
     q40.close()
     r = tinympc.TinyBatchSolver(pr.random_system(32, 16, 50), 4)    # wave-per-instance class
-    assert r.kernel_name().startswith("wavestream")
+    assert r.kernel_name().startswith("waveres")
     with pytest.raises(tinympc.TinyBatchError):
         r.set_storage(16)                                          # fp16 storage: row kernels only
     with pytest.raises(tinympc.TinyBatchError):
@@ -1149,14 +1155,14 @@ def test_per_instance_bounds_exact(tinympc, oracle_mod):
     table), fp16 storage and horizons without an unrolled instantiation run on the streaming row kernel, the nx = 32 class on
     the wave kernel, and update_slack works as a separate call — all bitwise equal to the oracle."""
     O, pr = oracle_mod, tinympc.problems
-    for prob, B, name in ((pr.quadrotor(20, 30), 37, "rowlane"), (pr.quadrotor(20, 17), 21, "rowstream"), (pr.random_system(32, 16, 50), 5, "wavestream")):
+    for prob, B, name in ((pr.quadrotor(20, 30), 37, "rowlane"), (pr.quadrotor(20, 17), 21, "rowstream"), (pr.random_system(32, 16, 50), 5, "waveres")):
         nx, nu, N = prob["nx"], prob["nu"], prob["N"]
         rng = np.random.default_rng(B)
         x0 = rng.uniform(-0.4, 0.4, size=(B, nx)).astype(np.float32)
         xref = (rng.standard_normal((N, nx)) * 0.1).astype(np.float32)
         bnds = tuple((a[None] * rng.uniform(0.05, 1.0, size=(B,) + a.shape)).astype(np.float32) for a in pr.bounds_arrays(prob))
         settings = dict(O.DEFAULT_SETTINGS, max_iter=25, check_termination=2)
-        for storage in ((32, 16) if name != "wavestream" else (32,)):
+        for storage in ((32, 16) if name != "waveres" else (32,)):
             sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
             sol.set_storage(storage)
             sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
@@ -1172,7 +1178,7 @@ def test_per_instance_bounds_exact(tinympc, oracle_mod):
                 orc.solve(st, *bn, R(xref), nthreads=8)
                 sol.solve()
                 assert_bitwise(sol.get_state(), st, f"per-instance bounds {sol.kernel_name()} k={k}")
-            if name != "wavestream":
+            if name != "waveres":
                 orc.step("update_slack", st, *bn, R(xref))
                 sol.update_slack()
                 assert_bitwise(sol.get_state(), st, "update_slack with per-instance bounds")
@@ -1221,10 +1227,11 @@ def test_randomised_differential_tools_short_run(tool):
     assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("dims", [(16, 8, 10), (16, 4, 12)])
+@pytest.mark.parametrize("dims", [(16, 8, 10), (16, 4, 12), (16, 4, 33), (16, 8, 49), (16, 4, 60)])
 def test_wave_kernel_other_classes(tinympc, oracle_mod, dims):
     """Two more classes of the wave-per-instance kernel, each pinned against its own reference build in test_oracle.py:
-    (16,8) takes Eigen's GEMV path like (32,16), (16,4) does not."""
+    (16,8) takes Eigen's GEMV path like (32,16), (16,4) does not.  Horizons on both sides of the register vectors' 32- and
+    48-step seams of the state-on-chip kernel, and one beyond its 50 steps (streaming kernel)."""
     O, pr = oracle_mod, tinympc.problems
     nx, nu, N = dims
     prob = pr.random_system(nx, nu, N, seed=nx * 100 + nu)
@@ -1235,7 +1242,7 @@ def test_wave_kernel_other_classes(tinympc, oracle_mod, dims):
     bnds = pr.bounds_arrays(prob)
     settings = dict(O.DEFAULT_SETTINGS, max_iter=40, check_termination=2)
     sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
-    assert sol.kernel_name() == f"wavestream<{nx},{nu},exact>", sol.kernel_name()
+    assert sol.kernel_name() == f"{'waveres' if N <= 50 else 'wavestream'}<{nx},{nu},exact>", sol.kernel_name()
     sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
     orc = O.Oracle(prob, np.float32, settings)
     st = O.new_state(B, nx, nu, N); st["x"][:, 0] = x0
