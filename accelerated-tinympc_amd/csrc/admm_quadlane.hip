@@ -63,10 +63,11 @@ __device__ __forceinline__ float quad_max(float v)
 }
 
 // MPC = true: closed-loop variant (P.mpc_steps MPC steps in one launch, the state staying in registers; see admm_rowlane.hip)
-template <int N, bool EXACT, bool H16, bool MPC = false>
+template <int N, bool EXACT, bool H16, bool MPC = false, bool D32 = false>
 __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
 {
     constexpr int NX = 4;
+    constexpr bool HD = H16 && !D32; // storage precision of the duals (gy)
     const int lane = threadIdx.x;
     const int j = lane & 3;
     const int inst = blockIdx.x * 16 + (lane >> 2);
@@ -125,8 +126,8 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
         pp[i] = cold ? 0.f : ldw<H16>(P.pd, rowx + i * 16);
         bx[i] = cold ? 0.f : ldw<H16>(P.vz, rowx + i * 16);
         bz[i] = (cold || i == N - 1) ? 0.f : ldw<H16>(P.vz, rowu + i * 16);
-        ax[i] = zdual ? 0.f : ldw<H16>(P.gy, rowx + i * 16);
-        ay[i] = (zdual || i == N - 1) ? 0.f : ldw<H16>(P.gy, rowu + i * 16);
+        ax[i] = zdual ? 0.f : ldw<HD>(P.gy, rowx + i * 16);
+        ay[i] = (zdual || i == N - 1) ? 0.f : ldw<HD>(P.gy, rowu + i * 16);
         sx[i] = 0.f; sz[i] = 0.f;
         if (i == N - 1) xrN = xr;
     }
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
                     const float2 lu = bnd[i * 16 + NX];
                     const float t0 = un + ay[i];                                         // admm.cpp:47
                     const float tz = __builtin_amdgcn_fmed3f(rnd<H16>(t0), lu.x, lu.y); // admm.cpp:51-54
-                    ay[i] = rnd<H16>(t0 - tz);                                           // admm.cpp:69
+                    ay[i] = rnd<HD>(t0 - tz);                                           // admm.cpp:69
                     pru = fmaxf(pru, fabsf(un - tz));                                    // admm.cpp:97
                     duu = fmaxf(duu, fabsf(bz[i] - tz));                                 // admm.cpp:98
                     sz[i] = tz;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
                 const float2 lx = bnd[i * 16 + j];
                 const float t0 = s + ax[i];                                              // admm.cpp:48
                 const float tx = __builtin_amdgcn_fmed3f(rnd<H16>(t0), lx.x, lx.y);     // admm.cpp:57-60
-                ax[i] = rnd<H16>(t0 - tx);                                               // admm.cpp:70
+                ax[i] = rnd<HD>(t0 - tx);                                               // admm.cpp:70
                 prx = fmaxf(prx, fabsf(s - tx));                                         // admm.cpp:95
                 dux = fmaxf(dux, fabsf(bx[i] - tx));                                     // admm.cpp:96
                 sx[i] = tx;
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
             stw<H16>(P.pd, ox, i == N - 1 ? pN : pp[i]);
             stw<H16>(P.vz, ox, bx[i]);
             stw<H16>(P.vzn, ox, sx[i]);
-            stw<H16>(P.gy, ox, ax[i]);
+            stw<HD>(P.gy, ox, ax[i]);
             if (lead)
             {
                 const bool inp = i < N - 1; // the input-type members have N-1 columns; column N-1 of the row layout is zero
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(WAVE) void admm_quadlane_kernel(const RowParams P)
                 stw<H16>(P.pd, ou, inp ? dl[i] : 0.f);
                 stw<H16>(P.vz, ou, inp ? bz[i] : 0.f);
                 stw<H16>(P.vzn, ou, inp ? sz[i] : 0.f);
-                stw<H16>(P.gy, ou, inp ? ay[i] : 0.f);
+                stw<HD>(P.gy, ou, inp ? ay[i] : 0.f);
             }
             s = xn;
         }
@@ -357,7 +358,7 @@ hipError_t launch_admm_quadlane(int N, bool exact, bool h16, const RowParams &P,
     const int nblocks = (P.batch + 15) / 16;
     if (P.mpc_steps > 1) // closed loop on chip: fp32 storage only
     {
-        if (h16) return hipErrorInvalidValue;
+        if (h16 || P.dual32) return hipErrorInvalidValue;
 #define TINY_QUADLANE_MPC_DISPATCH(NN)                                                                                   \
     if (N == NN)                                                                                                         \
     {                                                                                                                    \
@@ -366,6 +367,19 @@ hipError_t launch_admm_quadlane(int N, bool exact, bool h16, const RowParams &P,
         return hipGetLastError();                                                                                        \
     }
         TINY_FOR_EACH_QUADLANE(TINY_QUADLANE_MPC_DISPATCH)
+        return hipErrorInvalidValue;
+    }
+    if (P.dual32) // fp16 storage with fp32 duals
+    {
+        if (!h16) return hipErrorInvalidValue;
+#define TINY_QUADLANE_D32_DISPATCH(NN)                                                                                   \
+    if (N == NN)                                                                                                         \
+    {                                                                                                                    \
+        if (exact) hipLaunchKernelGGL((admm_quadlane_kernel<NN, true, true, false, true>), dim3(nblocks), dim3(WAVE), 0, stream, P);  \
+        else hipLaunchKernelGGL((admm_quadlane_kernel<NN, false, true, false, true>), dim3(nblocks), dim3(WAVE), 0, stream, P);      \
+        return hipGetLastError();                                                                                        \
+    }
+        TINY_FOR_EACH_QUADLANE(TINY_QUADLANE_D32_DISPATCH)
         return hipErrorInvalidValue;
     }
 #define TINY_QUADLANE_LAUNCH(NN, EX, H) \

@@ -36,9 +36,10 @@ namespace tinympc
 #define TINY_BPI_AHEAD 4
 #endif
 constexpr int BPI_AHEAD = TINY_BPI_AHEAD;
-template <int NX, int NU, int N, bool EXACT, bool H16, bool MPC = false, bool BPI = false>
+template <int NX, int NU, int N, bool EXACT, bool H16, bool MPC = false, bool BPI = false, bool D32 = false>
 __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P)
 {
+    constexpr bool HD = H16 && !D32; // storage precision of the duals (gy)
     const int lane = threadIdx.x;
     const int r16 = lane & 15;
     // dispatch order: workgroups start in index order, so order[] decides which instance groups start first
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             pd[i] = cold ? 0.f : ldw<H16>(P.pd, rowbase + i * 16); // live-in [p_i ; d_i]: kept by an instance that runs no backward sweep
             c[i] = is_x ? rnd<H16>(-(xr * qrow)) : pd[i];    // admm.cpp:81  q(i,j) = -(Xref(i,j) * Q(i))
             b[i * WAVE] = cold ? 0.f : ldw<H16>(P.vz, rowbase + i * 16);
-            a[i] = zdual ? 0.f : ldw<H16>(P.gy, rowbase + i * 16);
+            a[i] = zdual ? 0.f : ldw<HD>(P.gy, rowbase + i * 16);
             sn[i * WAVE] = 0.f;
             if (i == N - 1) xrN = xr;
         }
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
                 // admm.cpp:51-60: min(hi, max(lo, t)).  The host stores lo := min(lo, hi), which makes the median
                 // identical to that expression for every t (and +-inf where a bound is disabled).
                 t = __builtin_amdgcn_fmed3f(t, lh.x, lh.y);
-                a[i] = rnd<H16>((a[i] + sv) - t);          // admm.cpp:69-70
+                a[i] = rnd<HD>((a[i] + sv) - t);          // admm.cpp:69-70
                 pri = fmaxf(pri, fabsf(sv - t));           // admm.cpp:95,97
                 dua = fmaxf(dua, fabsf(b_pref - t));       // admm.cpp:96,98
                 sn[i * WAVE] = t;
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P
             stw<H16>(P.pd, o, i == N - 1 ? (is_x ? pN : 0.f) : pd[i]);
             stw<H16>(P.vz, o, b[i * WAVE]);
             stw<H16>(P.vzn, o, sni);
-            stw<H16>(P.gy, o, a[i]);
+            stw<HD>(P.gy, o, a[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (MPC) // the host's plant step continues from here
@@ -319,7 +320,7 @@ hipError_t launch_admm_rowlane(int nx, int nu, int N, bool exact, bool h16, cons
     const int nblocks = (P.batch + 3) / 4;
     if (P.mpc_steps > 1) // closed loop on chip: fp32 storage and batch-shared bounds only
     {
-        if (h16 || P.bounds_inst_stride != 0) return hipErrorInvalidValue;
+        if (h16 || P.dual32 || P.bounds_inst_stride != 0) return hipErrorInvalidValue;
 #define TINY_ROWLANE_MPC_DISPATCH(NX, NU, NN)                                                               \
     if (nx == NX && nu == NU && N == NN)                                                                    \
     {                                                                                                       \
@@ -332,7 +333,7 @@ hipError_t launch_admm_rowlane(int nx, int nu, int N, bool exact, bool h16, cons
     }
     if (P.bounds_inst_stride != 0) // per-instance bounds: fp32 storage only (fp16 storage with them runs on the streaming row kernel)
     {
-        if (h16) return hipErrorInvalidValue;
+        if (h16 || P.dual32) return hipErrorInvalidValue;
 #define TINY_ROWLANE_BPI_DISPATCH(NX, NU, NN)                                                                            \
     if (nx == NX && nu == NU && N == NN)                                                                                 \
     {                                                                                                                    \
@@ -341,6 +342,19 @@ hipError_t launch_admm_rowlane(int nx, int nu, int N, bool exact, bool h16, cons
         return hipGetLastError();                                                                                        \
     }
         TINY_FOR_EACH_ROWLANE(TINY_ROWLANE_BPI_DISPATCH)
+        return hipErrorInvalidValue;
+    }
+    if (P.dual32) // fp16 storage with fp32 duals
+    {
+        if (!h16) return hipErrorInvalidValue;
+#define TINY_ROWLANE_D32_DISPATCH(NX, NU, NN)                                                                            \
+    if (nx == NX && nu == NU && N == NN)                                                                                 \
+    {                                                                                                                    \
+        if (exact) hipLaunchKernelGGL((admm_rowlane_kernel<NX, NU, NN, true, true, false, false, true>), dim3(nblocks), dim3(WAVE), 0, stream, P);  \
+        else hipLaunchKernelGGL((admm_rowlane_kernel<NX, NU, NN, false, true, false, false, true>), dim3(nblocks), dim3(WAVE), 0, stream, P);      \
+        return hipGetLastError();                                                                                        \
+    }
+        TINY_FOR_EACH_ROWLANE(TINY_ROWLANE_D32_DISPATCH)
         return hipErrorInvalidValue;
     }
 #define TINY_ROWLANE_LAUNCH(NX, NU, NN, EX, H) \

@@ -38,9 +38,18 @@ namespace tinympc
 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef TINY_T16_ABLATE
+#define TINY_T16_ABLATE 0
+#endif
 
+#if TINY_T16_ABLATE == 1 // timing experiment: no matrix-core work (results are wrong)
+__device__ __forceinline__ f32x4 t16_fake4(float a, float b, f32x4 c) { c[0] += a; c[1] += b; c[2] += a; c[3] += b; return c; }
+#define TINY_MFMA4(a, b, c) t16_fake4((a), (b), (c))
+#define TINY_MFMA1(a, b, c) __builtin_amdgcn_mfma_f32_16x16x1f32((a), (b), (c), 0, 0, 0)
+#else
 #define TINY_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define TINY_MFMA1(a, b, c) __builtin_amdgcn_mfma_f32_16x16x1f32((a), (b), (c), 0, 0, 0)
+#endif
 
 // products of K-slices 0..2 for output register V: t[k] = M[row 4V+g][k] * s[k], k = 0..11
 template <int V>
@@ -351,6 +360,10 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
             const float4 lo = bloI[i * 4 + g], hi = bhiI[i * 4 + g], ol = snI[i * WAVE];
             const float lov[4] = {lo.x, lo.y, lo.z, lo.w}, hiv[4] = {hi.x, hi.y, hi.z, hi.w}, old[4] = {ol.x, ol.y, ol.z, ol.w};
             float t[4], an[4];
+#if TINY_T16_ABLATE == 2 // timing experiment: no slack / dual / residual arithmetic (results are wrong)
+#pragma unroll
+            for (int v = 0; v < 4; v++) { t[v] = sv[v]; an[v] = a[i][v]; }
+#else
 #pragma unroll
             for (int v = 0; v < 4; v++)
             {
@@ -361,6 +374,7 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
                 if (v < 3) { pri_x = fmaxf(pri_x, dp); dua_x = fmaxf(dua_x, dd_); }
                 else { pri_u = fmaxf(pri_u, dp); dua_u = fmaxf(dua_u, dd_); }
             }
+#endif
             masked_forward_update(amask, a[i], an, bo[i], old, sn_addr + i * (WAVE * 16), t);
             if (i == N - 1)
             {

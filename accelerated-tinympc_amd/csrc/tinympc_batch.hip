@@ -286,6 +286,7 @@ struct TinyBatch
     int variant = VAR_AUTO;
     int row_family_forced = -1; // tiny_batch_set_row_kernel
     bool h16 = false; // ROW-layout arrays, Xref and bounds stored as IEEE binary16 (tiny_batch_set_storage)
+    bool dual32 = false; // with h16: the duals pair gy stays fp32 (tiny_batch_set_storage_ex)
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -330,13 +331,15 @@ int dev_alloc_zero(float **p, size_t nfloats)
 
 float *work_ptr(TinyBatch *tb, int id) { return tb->layout == LAYOUT_ROW ? tb->pair[kPairOf[id]] : tb->arr[id]; }
 int h16_of(const TinyBatch *tb, int layout) { return (tb->h16 && layout == LAYOUT_ROW) ? 1 : 0; }
+// element type of one device array: the duals pair is fp32 under tiny_batch_set_storage_ex(16, 32)
+int h16_at(const TinyBatch *tb, int layout, const float *arr) { return (h16_of(tb, layout) && !(tb->dual32 && arr == tb->pair[5])) ? 1 : 0; }
 
 int alloc_layout(TinyBatch *tb, int layout)
 {
     if (layout == LAYOUT_ROW)
     {
         for (int p = 0; p < 6; p++)
-            if (!tb->pair[p]) TRY(dev_alloc_zero(&tb->pair[p], tb->h16 ? (tb->pair_floats + 1) / 2 : tb->pair_floats));
+            if (!tb->pair[p]) TRY(dev_alloc_zero(&tb->pair[p], (tb->h16 && !(tb->dual32 && p == 5)) ? (tb->pair_floats + 1) / 2 : tb->pair_floats));
     }
     else
     {
@@ -358,7 +361,7 @@ int launch_pack(TinyBatch *tb, const float *src, float *dst, int layout, int fam
 {
     const long long total = (long long)nb * nsteps * (fam ? tb->nu : tb->nx);
     hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(256), 0, tb->stream, src, dst, layout, geo(tb), fam, nb,
-                       shared ? 1 : 0, step0, nsteps, h16_of(tb, layout));
+                       shared ? 1 : 0, step0, nsteps, h16_at(tb, layout, dst));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -366,7 +369,7 @@ int launch_unpack(TinyBatch *tb, const float *src, float *dst, int layout, int f
 {
     const long long total = (long long)nb * nsteps * (fam ? tb->nu : tb->nx);
     hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(total)), dim3(256), 0, tb->stream, src, dst, layout, geo(tb), fam, nb,
-                       step0, nsteps, h16_of(tb, layout));
+                       step0, nsteps, h16_at(tb, layout, src));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -374,7 +377,7 @@ int launch_zero(TinyBatch *tb, float *dst, int layout, int fam, int step0, int n
 {
     const long long total = (long long)tb->batch * nsteps * (fam ? tb->nu : tb->nx);
     hipLaunchKernelGGL(zero_kernel, dim3(grid_for(total)), dim3(256), 0, tb->stream, dst, layout, geo(tb), fam, tb->batch,
-                       step0, nsteps, h16_of(tb, layout));
+                       step0, nsteps, h16_at(tb, layout, dst));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -763,7 +766,7 @@ void update_kname(TinyBatch *tb)
     char nm[96];
     const std::string keep = g_err;
     if (resolve_variant(tb, &v)) { tb->kname = "unsupported"; g_err = keep; return; }
-    const char *ar = v == VAR_ROW_EXACT ? "exact" : "fast", *sto = tb->h16 ? ",h16" : "";
+    const char *ar = v == VAR_ROW_EXACT ? "exact" : "fast", *sto = tb->h16 ? (tb->dual32 ? ",h16d" : ",h16") : "";
     if (v == VAR_STREAM) snprintf(nm, sizeof nm, "stream<%d,%d>", tb->NXC, tb->NUC);
     else if (row_family(tb) == 0) snprintf(nm, sizeof nm, "rowlane<%d,%d,%d,%s%s>", tb->nx, tb->nu, tb->N, ar, sto);
     else if (row_family(tb) == 1) snprintf(nm, sizeof nm, "rowloop<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
@@ -796,6 +799,7 @@ void fill_row_params(TinyBatch *tb, RowParams &P, bool exact)
     P.order = tb->order_dev;
     P.res = tb->res; P.status = tb->status; P.iter = tb->iter; P.n_unsolved = tb->n_unsolved;
     P.mpc_steps = 1; P.window_advance = 0; P.u0_traj = nullptr; P.x0buf = tb->x0buf;
+    P.dual32 = (tb->h16 && tb->dual32) ? 1 : 0;
 }
 
 int check_optional_terms(const TinyBatch *tb)
@@ -814,6 +818,7 @@ int run_step(TinyBatch *tb, int fn, int *converged_host, int *n_true)
         return fail(TINY_BATCH_ENOTREADY, "set_cache, set_dynamics and set_settings must be called first");
     if (!tb->rowmath_ok)
         return fail(TINY_BATCH_EUNSUPPORTED, "the single-function kernels need nx + nu <= 16 and an entry in TINY_FOR_EACH_ROWDIMS (nx=%d nu=%d)", tb->nx, tb->nu);
+    if (tb->dual32) return fail(TINY_BATCH_EUNSUPPORTED, "the single-function kernels do not implement fp16 storage with fp32 duals");
     TRY(check_optional_terms(tb));
     TRY(set_device(tb));
     if (tb->gains_dirty) TRY(pack_gains(tb));
@@ -885,7 +890,7 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
     HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, sizeof(int), tb->stream));
     // longest-first dispatch (dispatch_order.hip): predictor sweep + bucket sort ahead of the register-resident 16-lane kernels;
     // pays off only when the launch is several rounds of waves deep
-    const bool predicted_order = layout == LAYOUT_ROW && tb->dispatch_mode == 1 && !tb->order_dev && (row_family(tb) == 0 || row_family(tb) == 1) &&
+    const bool predicted_order = layout == LAYOUT_ROW && tb->dispatch_mode == 1 && !tb->order_dev && (row_family(tb) == 0 || row_family(tb) == 1) && !tb->dual32 &&
                                  tb->bpad4 / 4 >= kDispatchMinGroups && tb->max_iter > 1;
     if (predicted_order)
     {
@@ -926,6 +931,9 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
         fill_row_params(tb, P, v == VAR_ROW_EXACT);
         if (predicted_order) P.order = tb->order_buf;
         const int fam = row_family(tb);
+        if (P.dual32 && fam != 0 && fam != 4)
+            return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage with fp32 duals runs on the register-resident 16-lane and quad kernels only "
+                                                 "(batch-shared bounds, no optional terms, no forced row kernel)");
         e = fam == 0   ? launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
             : fam == 1 ? launch_admm_rowloop(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
             : fam == 3 ? launch_admm_wavestream(tb->nx, tb->nu, P, tb->stream)
@@ -1576,12 +1584,17 @@ int tiny_batch_set_row_kernel(TinyBatch *tb, int family)
     return 0;
 }
 
-int tiny_batch_set_storage(TinyBatch *tb, int bits)
+int tiny_batch_set_storage(TinyBatch *tb, int bits) { return tiny_batch_set_storage_ex(tb, bits, bits); }
+
+int tiny_batch_set_storage_ex(TinyBatch *tb, int bits, int dual_bits)
 {
     CHECK_TB(tb);
     if (bits != 16 && bits != 32) return fail(TINY_BATCH_EINVAL, "storage must be 32 (fp32, default) or 16 (IEEE binary16)");
-    const bool want = bits == 16;
-    if (want == tb->h16) return 0;
+    if (dual_bits != bits && !(bits == 16 && dual_bits == 32)) return fail(TINY_BATCH_EINVAL, "dual storage must equal the storage, or be 32 with 16-bit storage");
+    const bool want = bits == 16, want_d32 = want && dual_bits == 32;
+    if (want == tb->h16 && want_d32 == tb->dual32) return 0;
+    if (want_d32 && !(tb->row_dims_ok || tb->quad_ok))
+        return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage with fp32 duals needs a register-resident kernel instantiation (nx=%d nu=%d N=%d has none)", tb->nx, tb->nu, tb->N);
     if (want && !(tb->row_dims_ok || tb->rowmath_ok) )
         return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage is implemented by the row kernels only (nx=%d nu=%d has none)", tb->nx, tb->nu);
     if (want && tb->variant == VAR_STREAM) return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage cannot be combined with the streaming kernel");
@@ -1592,6 +1605,7 @@ int tiny_batch_set_storage(TinyBatch *tb, int bits)
     free_layout(tb, LAYOUT_TILE);
     free_layout(tb, LAYOUT_ROW);
     tb->h16 = want;
+    tb->dual32 = want_d32;
     tb->layout = (want || tb->row_dims_ok || tb->wave_ok || !tb->tile_dims_ok) ? LAYOUT_ROW : LAYOUT_TILE;
     TRY(alloc_layout(tb, tb->layout));
     HIP_TRY(hipMemsetAsync(tb->res, 0, (size_t)tb->batch * 4 * sizeof(float), tb->stream));

@@ -109,6 +109,7 @@ struct RowParams
     int mpc_steps, window_advance;
     float *u0_traj;              // [mpc_steps][batch][nu] or NULL: u.col(0) of every step
     float *x0buf;                // [batch][nx]: x0 of the LAST solve of the launch (the host's plant step reads it)
+    int dual32;                  // with fp16 storage: gy (the duals g, y) stays fp32 in HBM and is not rounded (rowlane and quadlane kernels only)
 };
 
 // (nx, nu) pairs with single-function kernels (admm_steps.hip), any N

@@ -70,7 +70,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch_mpc_step_async": [P, C.c_int], "tiny_batch_get_x0": [P, F],
         "tiny_batch_mpc_run_async": [P, C.c_int, C.c_int], "tiny_batch_mpc_run_traj_async": [P, C.c_int, C.c_int, P],
         "tiny_batch_enable_timing": [P, C.c_int], "tiny_batch_last_solve_ms": [P, F],
-        "tiny_batch_select_kernel": [P, C.c_int], "tiny_batch_set_storage": [P, C.c_int],
+        "tiny_batch_select_kernel": [P, C.c_int], "tiny_batch_set_storage": [P, C.c_int], "tiny_batch_set_storage_ex": [P, C.c_int, C.c_int],
         "tiny_batch_set_row_kernel": [P, C.c_int],
         "tiny_batch_set_dispatch": [P, C.c_int], "tiny_batch_set_dispatch_order_device": [P, P],
         "tiny_batch_set_optional_terms": [P, C.c_int, C.c_int], "tiny_batch_set_input_cost": [P, F],
@@ -382,9 +382,10 @@ class TinyBatchSolver:
         """Device pointer to a permutation of the ceil(batch/4) group indices (int32), or None."""
         self._check(self.lib.tiny_batch_set_dispatch_order_device(self._h, C.c_void_p(d_order_ptr)))
 
-    def set_storage(self, bits: int):
-        """32 = fp32 work arrays (default); 16 = IEEE binary16 storage with fp32 arithmetic.  Restarts the workspace."""
-        self._check(self.lib.tiny_batch_set_storage(self._h, bits))
+    def set_storage(self, bits: int, dual_bits: int | None = None):
+        """32 = fp32 work arrays (default); 16 = IEEE binary16 storage with fp32 arithmetic; dual_bits=32 with bits=16 keeps
+        the duals y, g in fp32.  Restarts the workspace."""
+        self._check(self.lib.tiny_batch_set_storage_ex(self._h, bits, bits if dual_bits is None else dual_bits))
 
     def set_stream(self, stream_ptr: int):
         self._check(self.lib.tiny_batch_set_stream(self._h, C.c_void_p(stream_ptr)))

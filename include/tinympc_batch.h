@@ -191,6 +191,14 @@ extern "C"
      * reductions stay fp32.  Row kernels only (nx + nu <= 16, batch-shared bounds).  Host-side arrays stay float; values
      * are rounded when they are stored.  Changing the precision restarts the workspace from zero, like create. */
     int tiny_batch_set_storage(TinyBatch *tb, int bits);
+    /* The same with the precision of the DUALS y, g chosen separately: (32, 32) and (16, 16) are tiny_batch_set_storage;
+     * (16, 32) keeps the duals — the running sums of the primal residuals, admm.cpp:69-70 — in fp32 while the other ten
+     * work arrays, Xref and the bounds are binary16 ("fp16 states, fp32 residual accumulation" read literally).  With fp16
+     * duals, increments below half an fp16 ulp of y, g are lost and part of a batch stalls short of the tolerances
+     * (DESIGN.md, configs[4]); fp32 duals remove that at 1/12 more state traffic.  Register-resident kernels only (rowlane
+     * and quadlane: an instantiated (nx, nu, N), batch-shared bounds, no optional terms); anything else returns
+     * TINY_BATCH_EUNSUPPORTED from solve. */
+    int tiny_batch_set_storage_ex(TinyBatch *tb, int bits, int dual_bits);
 
     /* Dispatch order of the register-resident 16-lane row kernels, unrolled and rolled (a launch of batch/4 workgroups is a
      * few rounds deep and iteration counts are uneven, so what starts last decides when the launch ends; results never depend on the order).

@@ -55,10 +55,10 @@ class _Dtype:
     (float32 arrays holding fp16-representable values; see the header of tinympc_oracle_impl.h)."""
 
     def __init__(self, dt):
-        self.h16 = isinstance(dt, str) and dt == "h16"
+        self.h16 = isinstance(dt, str) and dt in ("h16", "h16d")   # "h16d": fp16 primal arrays, fp32 duals y, g
         self.np = np.dtype(np.float32 if self.h16 else dt)
         self.ct = C.c_float if self.np == np.float32 else C.c_double
-        self.suf = "h16" if self.h16 else ("f32" if self.np == np.float32 else "f64")
+        self.suf = dt if self.h16 else ("f32" if self.np == np.float32 else "f64")
 
 
 def round_h16(a):

@@ -59,6 +59,7 @@ float oracle_round_h16(float f)
 }
 
 #define ST(x) (x)
+#define STD(x) (x)
 #define REAL float
 #define PS 4
 #define SUF(name) name##_f32
@@ -67,9 +68,11 @@ float oracle_round_h16(float f)
 #undef SUF
 #undef PS
 #undef ST
+#undef STD
 
 /* fp16 storage / fp32 arithmetic (see the header of tinympc_oracle_impl.h) */
 #define ST(x) oracle_round_h16(x)
+#define STD(x) oracle_round_h16(x)
 #define REAL float
 #define PS 4
 #define SUF(name) name##_h16
@@ -77,8 +80,20 @@ float oracle_round_h16(float f)
 #undef REAL
 #undef SUF
 #undef PS
+#undef STD
+/* ... with the duals y, g kept in fp32 */
+#define STD(x) (x)
+#define REAL float
+#define PS 4
+#define SUF(name) name##_h16d
+#include "tinympc_oracle_impl.h"
+#undef REAL
+#undef SUF
+#undef PS
 #undef ST
+#undef STD
 #define ST(x) (x)
+#define STD(x) (x)
 
 #define REAL double
 #define PS 2

@@ -12,6 +12,8 @@
  *   arithmetic" (BASELINE.json configs[4]) — every ASSIGNMENT to a TinyWorkspace array member rounds the stored value,
  *   products, sums, Eigen temporaries and the four residual reductions stay fp32.  The reference has no such mode, so
  *   the _h16 instantiation is pinned only through the _f32 one it is textually identical to apart from ST().
+ *   REAL=float  SUF(x)=x##_h16d: the same with the DUALS y, g kept in fp32 (STD(x) = x): "fp16 states, fp32 residual
+ *   accumulation" read literally — the duals are the running sums of the primal residuals.
  *
  * Every function names the reference lines it restates (paths relative to
  * /root/reference).  All matrices are column-major, exactly like the Eigen
@@ -208,10 +210,11 @@ void SUF(oracle_update_slack)(const SUF(OracleProblem) * P, SUF(OracleWork) * W)
 void SUF(oracle_update_dual)(const SUF(OracleProblem) * P, SUF(OracleWork) * W)
 {
     const int nxt = P->nx * P->N, nut = P->nu * (P->N - 1);
+    /* STD: the storage rounding of the DUALS; == ST except in the _h16d instantiation (fp16 primal arrays, fp32 duals) */
     for (int e = 0; e < nut; e++)
-        W->y[e] = ST(W->y[e] + W->u[e] - W->znew[e]);
+        W->y[e] = STD(W->y[e] + W->u[e] - W->znew[e]);
     for (int e = 0; e < nxt; e++)
-        W->g[e] = ST(W->g[e] + W->x[e] - W->vnew[e]);
+        W->g[e] = STD(W->g[e] + W->x[e] - W->vnew[e]);
 }
 
 /* src/tinympc/admm.cpp:77-85 */

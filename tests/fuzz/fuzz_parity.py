@@ -67,7 +67,7 @@ while time.time() < t_end:
     if h16:
         sol.set_storage(16)
     R = O.round_h16 if h16 else (lambda a: a)
-    fams = [0] + ([f for f in (1, 2, 3, 4) if not wave])
+    fams = [0] + ([1, 2, 3, 4, 5] if not wave else [6, 7])   # 5 = tile16 (MFMA products), 6 / 7 = streaming / on-chip wave kernel
     fam = int(rng.choice(fams))
     try:
         sol.set_row_kernel(fam)

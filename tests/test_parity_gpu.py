@@ -831,6 +831,79 @@ def test_fp16_storage_vs_oracle(tinympc, oracle_mod, case, variant_name):
     sol.close()
 
 
+@pytest.mark.parametrize("variant_name", ["row_exact", "row_fast"])
+@pytest.mark.parametrize("case", ["quad30", "cartpole10"])
+def test_fp16_storage_with_fp32_duals_vs_oracle(tinympc, oracle_mod, case, variant_name):
+    """tiny_batch_set_storage_ex(16, 32): ten work arrays, Xref and bounds in binary16, the duals y, g in fp32.  The
+    oracle's _h16d instantiation restates it (STD() = identity on the two assignments of admm.cpp:69-70); exact arithmetic
+    equals it bit for bit, fast arithmetic is held to the bar of the all-fp16 mode above (duals scaled by their primal array)."""
+    O, pr = oracle_mod, tinympc.problems
+    exact = VARIANTS[variant_name][1]
+    kind, N = H16_CASES[case]
+    prob = pr.quadrotor(20, N) if kind == "quad" else pr.cartpole(N)
+    nx, nu = prob["nx"], prob["nu"]
+    B = 203
+    rng = np.random.default_rng(N + nx + 1)
+    x0 = rng.uniform(-0.3, 0.3, size=(B, nx)).astype(np.float32)
+    xref = (rng.standard_normal((B, N, nx)) * 0.1).astype(np.float32)
+    bnds = pr.bounds_arrays(prob)
+    settings = dict(O.DEFAULT_SETTINGS, max_iter=80)
+    sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+    sol.select_kernel(VARIANTS[variant_name][0])
+    sol.set_storage(16, 32)
+    assert sol.kernel_name().endswith(",h16d>"), sol.kernel_name()
+    sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
+    orc = O.Oracle(prob, "h16d", settings)
+    bnds_h, xref_h = tuple(O.round_h16(b) for b in bnds), O.round_h16(xref)
+    st = O.new_state(B, nx, nu, N)
+    st["x"][:, 0] = O.round_h16(x0)
+    for k in range(3):  # cold start, then two WARM starts that keep the fp32 duals
+        if k == 1:
+            st["y"][:] = 0; st["g"][:] = 0
+            sol.reset_dual_variables()
+        st32 = O.copy_state(st)
+        orc.solve(st, *bnds_h, xref_h, nthreads=8)
+        sol.solve()
+        got = sol.get_state()
+        for name in STATE_ORDER:
+            if name not in ("g", "y"):
+                assert np.array_equal(got[name], O.round_h16(got[name])), f"{name} is not binary16-representable"
+        if exact:
+            assert_bitwise(got, st, f"h16d {case} k={k}")
+        else:
+            O.Oracle(prob, np.float32, settings).solve(st32, *bnds_h, xref_h, nthreads=8)  # the quantisation yardstick
+            same32 = st32["iter"] == st["iter"]
+            same = (got["iter"] == st["iter"]) & (got["status"] == st["status"])
+            f32flips = float((~same32).mean())
+            assert (~same).mean() <= max(1.5 * f32flips, 0.02) + 1.0 / B, \
+                f"h16d fast {case} k={k}: {(~same).mean():.2f} change the iteration count; fp16 storage itself changes {f32flips:.2f} vs fp32"
+            for name in STATE_ORDER:
+                # a dual is a sum of differences of binary16 values: flipped fp16 bits of x (u) move g (y) by ulps of x (u)
+                ref = {"g": "x", "y": "u"}.get(name, name)
+                scale = max(float(np.abs(st[ref]).max()), 1e-2)
+                err = np.abs(got[name][same].astype(np.float64) - st[name][same]).max() / scale
+                sel = same32 if same32.any() else slice(None)
+                spread = np.abs(st32[name][sel].astype(np.float64) - st[name][sel]).max() / scale
+                assert err <= max(4 * 2.0 ** -10, 4 * spread), \
+                    f"h16d fast {case} k={k}: {name} off by {err:.2e} of the magnitude of {ref} (storage spread {spread:.2e})"
+            sol.set_state(st)
+    # the duals round-trip through the accessors as fp32, the primal arrays as binary16
+    gnew = (st["g"] + np.float32(1e-5)).astype(np.float32)
+    sol.set_array("g", gnew)
+    assert np.array_equal(sol.get_array("g"), gnew)
+    sol.set_array("d", st["d"] + np.float32(1e-4))
+    assert np.array_equal(sol.get_array("d"), O.round_h16(st["d"] + np.float32(1e-4)))
+    # outside the register-resident kernels the mode is refused, loudly
+    sol.set_bounds(*[np.broadcast_to(b, (B,) + b.shape).copy() for b in bnds])  # per-instance bounds -> streaming row kernel
+    with pytest.raises(tinympc.TinyBatchError):
+        sol.solve()
+    sol.close()
+    s2 = tinympc.TinyBatchSolver(pr.quadrotor(20, 17), 8, settings=settings)  # no rowlane instantiation for N = 17
+    with pytest.raises(tinympc.TinyBatchError):
+        s2.set_storage(16, 32)
+    s2.close()
+
+
 def test_fp16_storage_step_functions(tinympc, oracle_mod):
     """The six step functions under fp16 storage: each equals the oracle's _h16 restatement bit for bit."""
     O, pr = oracle_mod, tinympc.problems
@@ -1691,7 +1764,8 @@ def test_tile16_kernel_equals_row_kernel_bitwise(tinympc, oracle_mod, exact):
             s2.close()
 
 
-def test_config5_fp16_storage_against_the_fp32_reference(tinympc, oracle_mod):
+@pytest.mark.parametrize("dual_bits", [16, 32])
+def test_config5_fp16_storage_against_the_fp32_reference(tinympc, oracle_mod, dual_bits):
     """BASELINE.json configs[4] as stated: a mixed batch (cartpole + quadrotor tracking) in one tiny_batch_group_solve call
     with fp16 storage and fp32 arithmetic / residual accumulation, held against the PINNED fp32 oracle (== the compiled
     reference) — not against the _h16 restatement, which the reference has no counterpart for.  SURVEY.md §8(d) asks for a
@@ -1704,21 +1778,25 @@ def test_config5_fp16_storage_against_the_fp32_reference(tinympc, oracle_mod):
         resolution near |x| ~ 1-2 (1e-3 .. 2e-3) is coarser than the 1e-3 residual tolerance, so some instances stall above it;
       * iteration-count drift of the instances that converge in both precisions: the count changes for 99.8 % of the
         quadrotor and 25 % of the cartpole instances; mean drift -8.7 / -1.7 iterations (the coarser slack reaches the
-        tolerance earlier); bars |mean drift| <= 12 / <= 4."""
+        tolerance earlier); bars |mean drift| <= 12 / <= 4.
+    dual_bits = 32 (tiny_batch_set_storage_ex(16, 32), the duals kept in fp32): the stall caused by dual increments lost
+    below an fp16 ulp goes away — cartpole converges 0.982 (above fp32's 0.974), bar >= 0.95; the quadrotor's remaining
+    stall is the PRIMAL quantisation (rho x one fp16 ulp of v > abs_dua_tol): 0.934, bar >= 0.90.  Same u0 bars."""
     O, pr = oracle_mod, tinympc.problems
     B = 8192
     cases = []
     cp = pr.cartpole(10)
     rng = np.random.default_rng(1)
     x0c = (np.array([[0, 0, 0.1, 0]], np.float32) + rng.uniform(-0.05, 0.05, size=(B, 4))).astype(np.float32)
-    cases.append(("cartpole", cp, x0c, np.zeros((10, 4), np.float32), dict(O.DEFAULT_SETTINGS, max_iter=150), None, 5e-3, 0.65, 4.0))
+    cases.append(("cartpole", cp, x0c, np.zeros((10, 4), np.float32), dict(O.DEFAULT_SETTINGS, max_iter=150), None, 5e-3,
+                  0.65 if dual_bits == 16 else 0.95, 4.0))
     qd = pr.quadrotor(20, 30)
     x0q, table, start = pr.tracking_batch(B, 30)
-    cases.append(("quadrotor", qd, x0q, pr.expand_windows(table, start, 30), dict(O.DEFAULT_SETTINGS), (table, start), 2e-2, 0.88, 12.0))
+    cases.append(("quadrotor", qd, x0q, pr.expand_windows(table, start, 30), dict(O.DEFAULT_SETTINGS), (table, start), 2e-2, 0.88 if dual_bits == 16 else 0.90, 12.0))
     sols = []
     for name, prob, x0, xref, settings, window, _, _, _ in cases:
         sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
-        sol.set_storage(16)
+        sol.set_storage(16, dual_bits)
         sol.set_bounds(*pr.bounds_arrays(prob))
         if window is not None:
             sol.set_xref_window(*window)
@@ -1731,7 +1809,7 @@ def test_config5_fp16_storage_against_the_fp32_reference(tinympc, oracle_mod):
     for (name, prob, x0, xref, settings, window, u_bar, conv_bar, _), sol in zip(cases, sols):
         nx, nu, N = prob["nx"], prob["nu"], prob["N"]
         got = sol.get_state()
-        assert sol.kernel_name().endswith(",h16>"), sol.kernel_name()
+        assert sol.kernel_name().endswith(",h16>" if dual_bits == 16 else ",h16d>"), sol.kernel_name()
         st = O.new_state(B, nx, nu, N); st["x"][:, 0] = x0
         O.Oracle(prob, np.float32, settings).solve(st, *pr.bounds_arrays(prob), xref, nthreads=8)   # the pinned fp32 reference
         both = (got["status"] == 1) & (st["status"] == 1)
@@ -1742,7 +1820,7 @@ def test_config5_fp16_storage_against_the_fp32_reference(tinympc, oracle_mod):
                             u0_err_max=float(err.max()), u0_err_p99=float(np.percentile(err, 99)), changed=float((drift != 0).mean()),
                             mean_drift=float(drift.mean()), mean_iter_h16=float(got["iter"].mean()), mean_iter_f32=float(st["iter"].mean()))
         sol.close()
-    print("config 5 (fp16 storage vs fp32 reference):", report)
+    print(f"config 5 (fp16 storage, {dual_bits}-bit duals, vs fp32 reference):", report)
     for (name, _, _, _, _, _, u_bar, conv_bar, drift_bar) in cases:
         r = report[name]
         assert r["conv_h16"] >= conv_bar, (name, r)
