@@ -1,4 +1,4 @@
-// admm_waveres.hip — state-on-chip exact kernel for problem classes with 16 < nx + nu <= 64 and N <= 50
+// admm_waveres.hip — state-on-chip kernel (exact and fma arithmetic) for problem classes with 16 < nx + nu <= 64 and N <= 50
 // (BASELINE.json configs[3]: nx = 32, nu = 16, N = 50): ONE WAVEFRONT = ONE INSTANCE, the loop-carried state in registers/LDS.
 //
 // Same mapping, arithmetic and results as admm_wave.hip (lane r owns row r of [x ; u]; wave_math.h: bitwise equal to the
@@ -31,7 +31,7 @@ struct StepRegs
     __device__ __forceinline__ float get(int i) const { return i < 32 ? lo[i] : (i < 48 ? mid[i - 32] : (i == 48 ? t0 : t1)); }
 };
 
-template <int NX, int NU>
+template <int NX, int NU, bool EXACT>
 __global__ __launch_bounds__(WAVE, 2) void admm_waveres_kernel(const RowParams P)
 {
     using PL = WavePlans<NX, NU>;
@@ -89,8 +89,12 @@ __global__ __launch_bounds__(WAVE, 2) void admm_waveres_kernel(const RowParams P
         float PT[NX], t[NX]; // -(Xref_{N-1}^T Pinf) (admm.cpp:83), x rows; PT[k] = Pinf(k, r)
 #pragma unroll
         for (int k = 0; k < NX; k++) PT[k] = P.mats[(2 * NX + 2 * NU + 1 + k) * WAVE + lane];
-        lane_products<0, NX>(t, xrN, PT, vec, lane);
-        pterm = -wreduce<PL::TERM>(t);
+        if constexpr (EXACT)
+        {
+            lane_products<0, NX>(t, xrN, PT, vec, lane);
+            pterm = -wreduce<PL::TERM>(t);
+        }
+        else pterm = -lane_fma_dot<0, NX>(0.f, xrN, PT, vec, lane);
     }
     int st = TINY_STATUS_UNSOLVED_, itn = 1;
     float r_ps = 0.f, r_pi = 0.f, r_ds = 0.f, r_di = 0.f;
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_waveres_kernel(const RowParams P
         // one horizon step: ai/ci = this step's dual and feed-forward; returns the new dual
         auto fwd_step = [&](int i, float ai, float ci) {
             float sv, xn = 0.f;
-            if (i < N - 1) wave_lqr_step<NX, NU>(G, vec, lane, is_x, is_u, s, ci, sv, xn);
+            if (i < N - 1) wave_lqr_step<NX, NU, EXACT>(G, vec, lane, is_x, is_u, s, ci, sv, xn);
             else sv = is_x ? s : 0.f;
             const float t0 = sv + ai;                                   // admm.cpp:47-48 and the sum of :69-70
             const float t = __builtin_amdgcn_fmed3f(t0, lh.x, lh.y);    // admm.cpp:51-60 (lo := min(lo, hi) on the host)
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_waveres_kernel(const RowParams P
         for (int i = 32; i < (N < 48 ? N : 48); i++) a.mid[i - 32] = fwd_step(i, a.mid[i - 32], c.mid[i - 32]);
         if (N > 48) a.t0 = fwd_step(48, a.t0, c.t0);
         if (N > 49) a.t1 = fwd_step(49, a.t1, c.t1);
-        pN = pterm - rho * t1; // admm.cpp:83-84
+        pN = EXACT ? pterm - rho * t1 : __builtin_fmaf(-rho, t1, pterm); // admm.cpp:83-84
         const float pri_x = wave_max(is_x ? pri : 0.f), dua_x = wave_max(is_x ? dua : 0.f);
         const float pri_u = wave_max(is_u ? pri : 0.f), dua_u = wave_max(is_u ? dua : 0.f);
         itn = it + 1;
@@ -170,7 +174,8 @@ __global__ __launch_bounds__(WAVE, 2) void admm_waveres_kernel(const RowParams P
         auto bwd_step = [&](int i, float ai, float ci) {
             const float cq = is_x ? ci : -0.f; // x rows: -(Xref.*Q); u rows: -0 (r = -rho*(znew - y) keeps the sign of a zero difference)
             float pn, dd;
-            wave_riccati_step<NX, NU>(G, vec, lane, is_x, p, cq - rho * (sn_cur - ai), pn, dd); // admm.cpp:19-20,80-82
+            const float lin = EXACT ? cq - rho * (sn_cur - ai) : __builtin_fmaf(-rho, sn_cur - ai, cq);
+            wave_riccati_step<NX, NU, EXACT>(G, vec, lane, is_x, p, lin, pn, dd); // admm.cpp:19-20,80-82
             P.pd[o] = is_u ? dd : pn; // [p_i ; d_i] of this sweep (live-out only)
             p = pn;
             sn_cur = b[(i > 0 ? i - 1 : 0) * WAVE];
@@ -204,12 +209,12 @@ __global__ __launch_bounds__(WAVE, 2) void admm_waveres_kernel(const RowParams P
             // x,u: regenerated from the d of the last executed forward sweep by the same instruction sequence
             const float ci = c.get(i), ai = a.get(i);
             float sv, xn = 0.f;
-            if (i < N - 1) wave_lqr_step<NX, NU>(G, vec, lane, is_x, is_u, s, ci, sv, xn);
+            if (i < N - 1) wave_lqr_step<NX, NU, EXACT>(G, vec, lane, is_x, is_u, s, ci, sv, xn);
             else sv = is_x ? s : 0.f;
             P.xu[o] = sv;
             s = xn;
             const float sni = b[i * WAVE];
-            const float lin = (is_x ? ci : -0.f) - rho * (sni - ai);
+            const float lin = EXACT ? (is_x ? ci : -0.f) - rho * (sni - ai) : __builtin_fmaf(-rho, sni - ai, is_x ? ci : -0.f);
             P.qr[o] = (i < N - 1 || is_x) ? lin : 0.f;
             if (i == N - 1) P.pd[o] = is_x ? pN : 0.f;
             else if (cold && !ran_bwd) P.pd[o] = 0.f;
@@ -231,13 +236,14 @@ __global__ __launch_bounds__(WAVE, 2) void admm_waveres_kernel(const RowParams P
 
 bool waveres_supported(int nx, int nu, int N) { return wavedims_supported(nx, nu) && N <= WAVERES_MAX_N; }
 
-hipError_t launch_admm_waveres(int nx, int nu, const RowParams &P, hipStream_t stream)
+hipError_t launch_admm_waveres(int nx, int nu, bool exact, const RowParams &P, hipStream_t stream)
 {
     const size_t ldsb = (size_t)(WAVE + P.N * WAVE) * sizeof(float);
 #define TINY_WAVERES_DISPATCH(NX, NU)                                                                             \
     if (nx == NX && nu == NU)                                                                                     \
     {                                                                                                             \
-        hipLaunchKernelGGL((admm_waveres_kernel<NX, NU>), dim3(P.batch), dim3(WAVE), ldsb, stream, P);            \
+        if (exact) hipLaunchKernelGGL((admm_waveres_kernel<NX, NU, true>), dim3(P.batch), dim3(WAVE), ldsb, stream, P);  \
+        else hipLaunchKernelGGL((admm_waveres_kernel<NX, NU, false>), dim3(P.batch), dim3(WAVE), ldsb, stream, P);       \
         return hipGetLastError();                                                                                 \
     }
     TINY_FOR_EACH_WAVEDIMS(TINY_WAVERES_DISPATCH)

@@ -712,6 +712,8 @@ int prepare_inputs(TinyBatch *tb, int layout)
     return 0;
 }
 
+int row_family(const TinyBatch *tb);
+
 int resolve_variant(TinyBatch *tb, int *out)
 {
     int v = tb->variant;
@@ -719,8 +721,8 @@ int resolve_variant(TinyBatch *tb, int *out)
     // per-instance bounds: the streaming row kernel and the wave kernel read them per instance; the register-resident
     // kernels stage ONE table in LDS and need batch-shared bounds
     const bool row_ok = tb->row_dims_ok || tb->rowmath_ok || tb->wave_ok;
-    if (tb->variant == VAR_ROW_FAST && tb->wave_ok)
-        return fail(TINY_BATCH_EUNSUPPORTED, "the wave-per-instance kernel (16 < nx + nu <= 64) has exact arithmetic only; fma arithmetic for these sizes is the streaming MFMA kernel (variant 1)");
+    if (tb->variant == VAR_ROW_FAST && tb->wave_ok && row_family(tb) != 6)
+        return fail(TINY_BATCH_EUNSUPPORTED, "fma arithmetic for 16 < nx + nu <= 64 needs the state-on-chip wave kernel (N <= 50); beyond that it is the streaming MFMA kernel (variant 1)");
     if (v == VAR_AUTO) v = row_ok ? VAR_ROW_EXACT : VAR_STREAM;
     if ((tb->en_uref || tb->en_d2p) && (!tb->rowmath_ok || v == VAR_STREAM))
         return fail(TINY_BATCH_EUNSUPPORTED, "the optional Uref / coeff_d2p terms (tiny_batch_set_optional_terms) are implemented by the row "
@@ -939,7 +941,7 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
             : fam == 3 ? launch_admm_wavestream(tb->nx, tb->nu, P, tb->stream)
             : fam == 4 ? launch_admm_quadlane(tb->N, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
             : fam == 5 ? launch_admm_tile16(tb->N, v == VAR_ROW_EXACT, P, tb->stream)
-            : fam == 6 ? launch_admm_waveres(tb->nx, tb->nu, P, tb->stream)
+            : fam == 6 ? launch_admm_waveres(tb->nx, tb->nu, v == VAR_ROW_EXACT, P, tb->stream)
                        : launch_admm_rowstream(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream);
     }
     if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));

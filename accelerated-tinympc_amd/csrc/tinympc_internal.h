@@ -145,7 +145,7 @@ bool wavedims_supported(int nx, int nu);
 hipError_t launch_admm_wavestream(int nx, int nu, const RowParams &P, hipStream_t stream);
 // the same classes with the loop-carried state on chip (admm_waveres.hip): N <= 50
 bool waveres_supported(int nx, int nu, int N);
-hipError_t launch_admm_waveres(int nx, int nu, const RowParams &P, hipStream_t stream);
+hipError_t launch_admm_waveres(int nx, int nu, bool exact, const RowParams &P, hipStream_t stream);
 
 hipError_t launch_admm_stream(int nxc, int nuc, const SolveParams &P, hipStream_t stream);
 

@@ -76,6 +76,31 @@ __device__ __forceinline__ void lane_products(float (&t)[CNT], float s, const fl
     }
 }
 
+// fma arithmetic: acc += sum_k M[k] * s[K0 + k], four interleaved fma chains (no order to keep), same LDS broadcast
+template <int K0, int CNT>
+__device__ __forceinline__ float lane_fma_dot(float acc, float s, const float (&M)[CNT], float *vec, int lane)
+{
+    vec[lane] = s;
+    if constexpr (K0 % 4 == 0 && CNT % 4 == 0)
+    {
+        float a0 = acc, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int k4 = 0; k4 < CNT / 4; k4++)
+        {
+            const float4 v = reinterpret_cast<const float4 *>(vec + K0)[k4];
+            a0 = __builtin_fmaf(M[4 * k4 + 0], v.x, a0); a1 = __builtin_fmaf(M[4 * k4 + 1], v.y, a1);
+            a2 = __builtin_fmaf(M[4 * k4 + 2], v.z, a2); a3 = __builtin_fmaf(M[4 * k4 + 3], v.w, a3);
+        }
+        return (a0 + a1) + (a2 + a3);
+    }
+    else
+    {
+#pragma unroll
+        for (int k = 0; k < CNT; k++) acc = __builtin_fmaf(M[k], vec[K0 + k], acc);
+        return acc;
+    }
+}
+
 template <int NX, int NU>
 struct WaveGains
 {
@@ -95,10 +120,18 @@ struct WaveGains
 };
 
 // forward_pass step (admm.cpp:31,35)
-template <int NX, int NU>
+template <int NX, int NU, bool EXACT = true>
 __device__ __forceinline__ void wave_lqr_step(const WaveGains<NX, NU> &G, float *vec, int lane, bool is_x, bool is_u, float s, float ci, float &sv, float &xn)
 {
     using PL = WavePlans<NX, NU>;
+    if constexpr (!EXACT)
+    {
+        const float acc = lane_fma_dot<0, NX>(0.f, s, G.M1, vec, lane); // u rows of M1 hold -Kinf (pack_gains, fast)
+        const float un = acc - ci;
+        xn = lane_fma_dot<NX, NU>(acc, un, G.M2, vec, lane);
+        sv = is_u ? un : s;
+        return;
+    }
     float t[NX];
     lane_products<0, NX>(t, s, G.M1, vec, lane);
     float acc;
@@ -112,10 +145,17 @@ __device__ __forceinline__ void wave_lqr_step(const WaveGains<NX, NU> &G, float 
 }
 
 // backward_pass_grad step (admm.cpp:19-20)
-template <int NX, int NU>
+template <int NX, int NU, bool EXACT = true>
 __device__ __forceinline__ void wave_riccati_step(const WaveGains<NX, NU> &G, float *vec, int lane, bool is_x, float p, float lin, float &pn, float &dd)
 {
     using PL = WavePlans<NX, NU>;
+    if constexpr (!EXACT)
+    {
+        const float wv = lane_fma_dot<0, NX>(lin, p, G.M3, vec, lane);  // q + AmBKt*p  |  Bdyn^T*p + r
+        dd = lane_fma_dot<NX, NU>(0.f, wv, G.M45, vec, lane);           // u rows: Quu_inv
+        pn = lane_fma_dot<NX, NU>(wv, lin, G.M45, vec, lane);           // x rows hold -Kinf^T (pack_gains, fast)
+        return;
+    }
     float t[NX];
     lane_products<0, NX>(t, p, G.M3, vec, lane);
     float dot;

@@ -172,7 +172,8 @@ extern "C"
     /* Force a kernel variant: 0 = auto (exact arithmetic when the class has an exact kernel — nx + nu <= 16: row
      * kernels, 16 < nx + nu <= 64: wave-per-instance kernel — and the bounds are batch-shared, else streaming),
      * 1 = streaming MFMA kernel (state in HBM, fma arithmetic), 2 = exact arithmetic (bitwise equal to the reference's
-     * SSE2 build), 3 = row kernels with fma arithmetic (nx + nu <= 16).  Bounds may be batch-shared or per instance in
+     * SSE2 build), 3 = fma arithmetic on the row kernels (nx + nu <= 16)
+     * or on the state-on-chip wave kernel (16 < nx + nu <= 64, N <= 50).  Bounds may be batch-shared or per instance in
      * every variant (per-instance bounds select the kernels that stream their state). */
     int tiny_batch_select_kernel(TinyBatch *tb, int variant);
     /* Which row kernel variants 2/3 (and auto) launch: 0 = auto (4 where it exists, else 1 where (nx,nu,N) has an unrolled

@@ -1027,13 +1027,50 @@ def test_wave_kernel_vs_oracle(tinympc, oracle_mod, B, wave_kernel):
             rc = sol.solve()
             assert rc == (1 if rc_ref else 0)
             assert_bitwise(sol.get_state(), st, f"wave B={B} {settings} k={k}")
-        with pytest.raises(tinympc.TinyBatchError):
-            sol.select_kernel(3)      # fma arithmetic for this class is the streaming kernel
-        sol.select_kernel(1)          # ... which takes over the same workspace
+        if wave_kernel == "wavestream":
+            with pytest.raises(tinympc.TinyBatchError):
+                sol.select_kernel(3)  # fma arithmetic for this class: the state-on-chip wave kernel or the streaming kernel
+        else:
+            sol.select_kernel(3)
+            assert sol.kernel_name() == "waveres<32,16,fast>", sol.kernel_name()
+        sol.select_kernel(1)          # the streaming MFMA kernel takes over the same workspace
         assert sol.kernel_name() == "stream<8,4>"
         got = sol.get_state()
         for name in STATE_ORDER:
             assert np.array_equal(got[name], st[name]), f"layout switch lost {name}"
+        sol.close()
+
+
+@pytest.mark.parametrize("dims", [(32, 16, 50), (16, 8, 49), (16, 4, 33)])
+def test_wave_kernel_fma_arithmetic(tinympc, oracle_mod, dims):
+    """fma arithmetic of the state-on-chip wave kernel (waveres<...,fast>): held to the bar of every other fma variant —
+    iteration counts and arrays within the reference's own fp64-vs-fp32 spread (compare_states) — over a warm-started
+    chain, with the early exit and with a fixed iteration count."""
+    O, pr = oracle_mod, tinympc.problems
+    nx, nu, N = dims
+    prob = pr.random_system(nx, nu, N)
+    B = 96
+    rng = np.random.default_rng(nx + N)
+    x0 = rng.uniform(-1, 1, size=(B, nx)).astype(np.float32)
+    xref = (rng.standard_normal((B, N, nx)) * 0.2).astype(np.float32)
+    bnds = pr.bounds_arrays(prob)
+    for extra, fixed in ((dict(max_iter=60), False), (dict(max_iter=9, abs_pri_tol=0.0, abs_dua_tol=0.0), True)):
+        settings = dict(O.DEFAULT_SETTINGS, **extra)
+        sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+        sol.select_kernel(3)
+        assert sol.kernel_name() == f"waveres<{nx},{nu},fast>", sol.kernel_name()
+        sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
+        orc = O.Oracle(prob, np.float32, settings, allow_unpinned_dims=True)
+        st = O.new_state(B, nx, nu, N); st["x"][:, 0] = x0
+        for k in range(3):
+            st["y"][:] = 0; st["g"][:] = 0
+            sol.reset_dual_variables()
+            pre = O.copy_state(st)
+            orc.solve(st, *bnds, xref, nthreads=8)
+            sol.solve()
+            ref64 = None if fixed else yardstick(O, prob, settings, pre, xref, bnds)
+            compare_states(sol.get_state(), st, prob, f"waveres fast {dims} {extra} k={k}", ref64=ref64, fixed=fixed)
+            sol.set_state(st)
         sol.close()
 
 
