@@ -67,13 +67,13 @@ measure("cfg3 tracking fixed 10 iters", q30, 65536, track(65536), (0, 3, 1), set
 
 
 # ---- cfg5 as BASELINE.json states it: mixed cartpole + quadrotor batch in ONE call, fp16 storage / fp32 arithmetic ----
-def group(storage, variant, reps=5):
+def group(storage, variant, reps=5, dual_bits=None):
     """32768 cartpole + 32768 quadrotor (tracking) instances solved by tiny_batch_group_solve; wall time of the group."""
     import ctypes
     sols, x0s = [], []
     for prob, setup, st in ((cp, cps, dict(max_iter=150)), (q30, track(32768), None)):
         sol = T.TinyBatchSolver(prob, 32768, settings=st)
-        sol.select_kernel(variant); sol.set_storage(storage)
+        sol.select_kernel(variant); sol.set_storage(storage, dual_bits)
         sol.set_bounds(*pr.bounds_arrays(prob))
         x0s.append(setup(sol)); sols.append(sol)
     ts = []
@@ -89,7 +89,8 @@ def group(storage, variant, reps=5):
         out.append((sol.kernel_name(), it.copy(), float(np.mean(stt == 1)), sol.get_u()[:, 0].copy()))
         sol.close()
     ms = float(np.median(ts))
-    print(f"cfg5 mixed 32768 cartpole + 32768 quadrotor, storage fp{storage}, variant {variant}: {ms:7.3f} ms wall per group "
+    dnote = "" if dual_bits in (None, storage) else f" (duals fp{dual_bits})"
+    print(f"cfg5 mixed 32768 cartpole + 32768 quadrotor, storage fp{storage}{dnote}, variant {variant}: {ms:7.3f} ms wall per group "
           f"-> {65536 / ms * 1e3:.4g} solves/s; " + "; ".join(f"{k}: mean iters {i.mean():.2f}, converged {c:.3f}" for k, i, c, _ in out))
     return out
 
@@ -97,6 +98,7 @@ def group(storage, variant, reps=5):
 for variant in (2, 3):
     ref = group(32, variant)
     h16 = group(16, variant)
+    group(16, variant, dual_bits=32)
     for (k32, i32, c32, u32), (k16, i16, c16, u16) in zip(ref, h16):
         same = i32 == i16
         du = np.abs(u16[same] - u32[same]).max() / max(np.abs(u32).max(), 1e-6) if same.any() else float("nan")
