@@ -34,7 +34,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 CLASSES = [("quad", 30), ("quad", 25), ("quad", 20), ("quad", 10), ("quad", 17), ("quad", 7), ("quad", 36), ("cartpole", 10),
            ("cartpole", 23), ("odd", 7), ("odd", 13), ("rand32", 50), ("r8_4", 9), ("r12_2", 14), ("r4_2", 8), ("r4_4", 35), ("w16_8", 10), ("w16_4", 12)]
-t_end, rounds, solves, t_note, overflowed = time.time() + budget, 0, 0, time.time(), 0
+t_end, rounds, solves, t_note, overflowed, refused = time.time() + budget, 0, 0, time.time(), 0, 0
 while time.time() < t_end:
     if time.time() - t_note > 30:
         print(f"... {rounds} rounds, {solves} solves so far", flush=True)
@@ -64,8 +64,14 @@ while time.time() < t_end:
     bnds_raw = bnds
     sol = T.TinyBatchSolver(prob, B, settings=settings)
     h16 = not wave and rng.random() < 0.3   # fp16 storage / fp32 arithmetic against the oracle's _h16 restatement
+    h16d = False
     if h16:
         sol.set_storage(16)
+        if rng.random() < 0.4:   # ... with the duals kept in fp32 (register-resident kernels only; refused elsewhere)
+            try:
+                sol.set_storage(16, 32); h16d = True
+            except T.TinyBatchError:
+                pass
     R = O.round_h16 if h16 else (lambda a: a)
     fams = [0] + ([1, 2, 3, 4, 5] if not wave else [6, 7])   # 5 = tile16 (MFMA products), 6 / 7 = streaming / on-chip wave kernel
     fam = int(rng.choice(fams))
@@ -113,13 +119,21 @@ while time.time() < t_end:
         sol.set_dispatch_order_device(d_order.value)
     elif rng.random() < 0.1:
         sol.set_dispatch(1)
-    orc = O.Oracle(prob, "h16" if h16 else np.float32, settings)
+    orc = O.Oracle(prob, ("h16d" if h16d else "h16") if h16 else np.float32, settings)
     if opt[0]:
         orc.set_uref(R(uref))
     for k in range(int(rng.integers(1, 4))):
         if rng.random() < 0.6:
             st["y"][:] = 0; st["g"][:] = 0; sol.reset_dual_variables()
-        orc.solve(st, *bnds, xref, nthreads=8); sol.solve(); solves += 1
+        if h16d:
+            try:
+                sol.solve()
+            except T.TinyBatchError:   # per-instance bounds, optional terms or a forced streaming kernel: refused by design
+                refused += 1
+                break
+            orc.solve(st, *bnds, xref, nthreads=8); solves += 1
+        else:
+            orc.solve(st, *bnds, xref, nthreads=8); sol.solve(); solves += 1
         if not all(np.all(np.isfinite(st[n_])) for n_ in O.STATE_ORDER):
             overflowed += 1   # NaN / inf regime (fp16 storage overflow, unstable iteration): behaviour undefined
             break
@@ -132,7 +146,7 @@ while time.time() < t_end:
             else:
                 same = np.array_equal(g_, r_)
             if not same:
-                print(f"MISMATCH round {rounds} h16={h16} {kind} N={N} B={B} kernel {sol.kernel_name()} settings {settings} xref mode {mode} solve {k}: {name}"
+                print(f"MISMATCH round {rounds} h16={h16} h16d={h16d} {kind} N={N} B={B} kernel {sol.kernel_name()} settings {settings} xref mode {mode} solve {k}: {name}"
                       f" | per-instance bounds {bnds_raw[0].ndim == 3}, row kernel family {fam}, caller order {d_order is not None}, optional terms {opt}")
                 bad = np.argwhere(~((got[name] == st[name]) & (np.signbit(got[name]) == np.signbit(st[name]))))
                 for idx in bad[:6]:
@@ -140,7 +154,7 @@ while time.time() < t_end:
                     print("   ", idx, "gpu", got[name][idx], "oracle", st[name][idx], "iter gpu/oracle", got["iter"][idx[0]], st["iter"][idx[0]])
                 sys.exit(1)
     finite = all(np.all(np.isfinite(st[n_])) for n_ in O.STATE_ORDER)
-    if finite and nx + nu <= 16 and rng.random() < 0.3:   # one of the six step functions on the state the chain left
+    if finite and nx + nu <= 16 and not h16d and rng.random() < 0.3:   # one of the six step functions on the state the chain left
         fn = O.Oracle.STEP_FUNCTIONS[rng.integers(6)]
         ref_rv = orc.step(fn, st, *bnds, xref)
         rv = getattr(sol, fn)()
@@ -156,4 +170,4 @@ while time.time() < t_end:
     if d_order is not None:
         hip.hipFree(d_order)
 print(f"fuzz ok: {rounds} rounds, {solves} solves, all bitwise equal to the oracle (signs of zeros included); "
-      f"{overflowed} rounds left the finite range and were not compared")
+      f"{overflowed} rounds left the finite range and were not compared; {refused} fp32-dual rounds asked for a kernel that does not implement them and were refused")
