@@ -65,14 +65,20 @@ table = json.loads(tf.read_text()) if tf.exists() else {}
 table = {k: v for k, v in table.items() if not k.startswith("void ")}
 def label(kname):
     import re
-    m = re.search(r"admm_rowlane_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)(?:, (true|false))?>", kname)
-    if m and m.group(6) != "true":   # the closed-loop (MPC) instantiation is a different workload
-        return f"rowlane<{m.group(1)},{m.group(2)},{m.group(3)},{'exact' if m.group(4) == 'true' else 'fast'}{',h16' if m.group(5) == 'true' else ''}>"
+    # template arguments: NX, NU, N, EXACT, H16, MPC (closed loop on chip), BPI (per-instance bounds), D32 (fp32 duals)
+    m = re.search(r"admm_rowlane_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)((?:, (?:true|false))*)>", kname)
+    if m:
+        rest = [t.strip() == "true" for t in m.group(6).split(",") if t.strip()] + [False] * 3
+        if not rest[0] and not rest[1]:   # the closed-loop and per-instance-bounds instantiations are different workloads
+            sto = (",h16d" if rest[2] else ",h16") if m.group(5) == "true" else ""
+            return f"rowlane<{m.group(1)},{m.group(2)},{m.group(3)},{'exact' if m.group(4) == 'true' else 'fast'}{sto}>"
     m = re.search(r"admm_stream_kernel<(\d+), (\d+)>", kname)
     if m:
         return f"stream<{m.group(1)},{m.group(2)}>"
-    m = re.search(r"admm_wave\w*_kernel<(\d+), (\d+)", kname)
-    return f"wavestream<{m.group(1)},{m.group(2)},exact>" if m else kname
+    m = re.search(r"admm_(wave\w*)_kernel<(\d+), (\d+)(?:, (true|false))?", kname)
+    if m:
+        return f"{'waveres' if m.group(1) == 'waveres' else 'wavestream'}<{m.group(2)},{m.group(3)},{'fast' if m.group(4) == 'false' else 'exact'}>"
+    return kname
 if line:
     sys.path.insert(0, str(ROOT))
     from bench import kernel_source_sha  # binds the figure to the kernel sources it was measured on (bench.py reports null once they change)
