@@ -301,6 +301,278 @@ __global__ __launch_bounds__(WAVE64) void admm_f64_kernel(const Params64 P)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// admm_f64_rows_kernel<NX,NU,N>: the 16-lanes-per-instance mapping of admm_rowlane.hip in double.  Lane r of a DPP row owns
+// row r of the stacked vector [x ; u] (nx + nu <= 16), four instances per wavefront, the horizon unrolled, and the whole
+// loop-carried state of the solve in registers: per step a = [g;y], c = [-(Xref.*Q) ; d], pd = [p;d] of the last backward
+// sweep, b = [v;z], sn = [vnew;znew] (five doubles per lane and step; one wave per SIMD owns the 512-entry register file).
+// The workspace arrays are read once before the first and written once after the last iteration — the thread-per-instance
+// kernel above moves every array through HBM in every iteration (3.7 GB per iteration of 65 536 quadrotor instances).
+// A state element is broadcast within its row by two v_mov_b32_dpp row_newbcast (low and high word), products and sums
+// are separately rounded v_mul_f64 / v_add_f64 in the same orders as above.  Results are bitwise equal to the
+// thread-per-instance kernel and to the compiled fp64 reference.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// t[k] = M[k] * s[K0 + k], s[j] = the value lane j of this lane's row holds (row_newbcast:j = 0x150 + j)
+template <int K0, int CNT, int K = 0>
+__device__ __forceinline__ void row_products(double (&t)[CNT], double s, const double (&M)[CNT])
+{
+    if constexpr (K < CNT)
+    {
+        t[K] = M[K] * dpp64<0x150 + K0 + K>(s);
+        row_products<K0, CNT, K + 1>(t, s, M);
+    }
+}
+__device__ __forceinline__ double row_max(double v) // max over the 16 lanes of a row, every lane gets it
+{
+    v = fmax(v, dpp64<0x128>(v)); v = fmax(v, dpp64<0x124>(v)); v = fmax(v, dpp64<0x122>(v)); v = fmax(v, dpp64<0x121>(v));
+    return v;
+}
+// the reference's order for a lazy product whose result has ROWS rows (see row_dot above)
+template <int ROWS, int CNT>
+__device__ __forceinline__ double lazy_sum(const double (&t)[CNT])
+{
+    static_assert(ROWS <= PS || ROWS % PS == 0, "results with rows > 2 and odd: the reference's order depends on alignment");
+    if constexpr (ROWS > 1 && ROWS % PS == 0) return seq_sum(t);
+    else if constexpr (ROWS == 1) return vec_sum(t);
+    else return novec_sum(t);
+}
+
+#define TINY_FOR_EACH_F64ROWS(X) X(12, 4, 10) X(12, 4, 30) X(12, 4, 20) X(4, 1, 10) X(8, 4, 9)
+constexpr int F64_AHEAD = 4; // bounds are fetched this many steps ahead of their use
+
+template <int NX, int NU, int N>
+__global__ __launch_bounds__(WAVE64, 1) void admm_f64_rows_kernel(const Params64 P, const double *__restrict__ gains)
+{
+    static_assert(NX + NU <= 16 && !(NX >= 8 && NU >= 8), "16-lane mapping; both dims >= 8 would take Eigen's GEMV kernel");
+    const int lane = threadIdx.x, r16 = lane & 15;
+    const int inst = blockIdx.x * 4 + (lane >> 4);
+    const bool valid = inst < P.batch;
+    const size_t b = valid ? inst : P.batch - 1; // loads of an out-of-range row address the last instance; it stores nothing
+    const bool is_x = r16 < NX, is_u = r16 >= NX && r16 < NX + NU;
+    const int row = is_x ? r16 : (is_u ? r16 - NX : 0);
+    const size_t bp = (size_t)P.bpad;
+    const double rho = P.rho;
+    // element (step, this lane's row) of the pair [x-type array ; u-type array]; u-type arrays have N - 1 steps
+    auto ld = [&](int idx, int idu, int i) -> double {
+        if (is_x) return P.arr[idx][((size_t)i * NX + row) * bp + b];
+        if (is_u && i < N - 1) return P.arr[idu][((size_t)i * NU + row) * bp + b];
+        return 0.0;
+    };
+    auto st = [&](int idx, int idu, int i, double v) {
+        if (!valid) return;
+        if (is_x) P.arr[idx][((size_t)i * NX + row) * bp + b] = v;
+        else if (is_u && i < N - 1) P.arr[idu][((size_t)i * NU + row) * bp + b] = v;
+    };
+    const bool en_b = is_x ? (P.en_state_bound != 0) : (is_u && P.en_input_bound != 0);
+    // this lane's bounds of step i sit at pl0[i * bstep], ph0[i * bstep] (u rows have N - 1 steps; the other lanes read x row 0, unused)
+    const size_t bstr = is_u ? (size_t)P.ub_stride : (size_t)P.xb_stride;
+    const size_t boff = (size_t)row * bstr + (bstr > 1 ? b : 0);
+    const double *const pl0 = (is_u ? P.umin : P.xmin) + boff, *const ph0 = (is_u ? P.umax : P.xmax) + boff;
+    const size_t bstep = (is_u ? NU : NX) * bstr;
+    if (P.max_iter <= 0) // tiny_solve only sets status and iter (admm.cpp:114-117,151)
+    {
+        if (valid && r16 == 0)
+        {
+            P.status[inst] = ST_UNSOLVED; P.iter[inst] = 1;
+            atomicAdd(P.n_unsolved, 1);
+        }
+        return;
+    }
+    // gains, one register per matrix column: [reg][16] doubles (pack_row_gains on the host)
+    double M1[NX], M2[NU], M3[NX], M45[NU];
+#pragma unroll
+    for (int k = 0; k < NX; k++) { M1[k] = gains[k * 16 + r16]; M3[k] = gains[(NX + NU + k) * 16 + r16]; }
+#pragma unroll
+    for (int m = 0; m < NU; m++) { M2[m] = gains[(NX + m) * 16 + r16]; M45[m] = gains[(2 * NX + NU + m) * 16 + r16]; }
+    const double qrow = gains[(2 * NX + 2 * NU) * 16 + r16];
+
+    // ---- live-in ----
+    // long horizons keep the two slack words of a step in LDS (lane-linear, 1 KB per step and wave), short ones in registers
+    constexpr bool LDS_SLACK = N > 20;
+    constexpr int NREG = LDS_SLACK ? 1 : N;
+    __shared__ double slack_lds[LDS_SLACK ? 2 * N * WAVE64 : 1];
+    double a[N], c[N], pd[N], bb_r[NREG], sn_r[NREG];
+    double *const sl = slack_lds + lane;
+#define BB_GET(i) (LDS_SLACK ? sl[(2 * (i)) * WAVE64] : bb_r[LDS_SLACK ? 0 : (i)])
+#define SN_GET(i) (LDS_SLACK ? sl[(2 * (i) + 1) * WAVE64] : sn_r[LDS_SLACK ? 0 : (i)])
+#define BB_SET(i, v) do { if constexpr (LDS_SLACK) sl[(2 * (i)) * WAVE64] = (v); else bb_r[LDS_SLACK ? 0 : (i)] = (v); } while (0)
+#define SN_SET(i, v) do { if constexpr (LDS_SLACK) sl[(2 * (i) + 1) * WAVE64] = (v); else sn_r[LDS_SLACK ? 0 : (i)] = (v); } while (0)
+    double xrN = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+    {
+        double xr = 0.0;
+        if (is_x) xr = P.xref[((size_t)i * NX + row) * (size_t)P.xref_stride + (P.xref_stride > 1 ? b : 0)];
+        pd[i] = ld(TINY_ARR_P, TINY_ARR_D, i);
+        c[i] = is_x ? -(xr * qrow) : pd[i];          // admm.cpp:81 | d_i
+        a[i] = ld(TINY_ARR_G, TINY_ARR_Y, i);
+        BB_SET(i, ld(TINY_ARR_V, TINY_ARR_Z, i));
+        SN_SET(i, 0.0);
+        if (i == N - 1) xrN = xr;
+    }
+    const double x0 = ld(TINY_ARR_X, TINY_ARR_U, 0); // x.col(0) on the x rows
+    double pterm;
+    {
+        double PT[NX], t[NX]; // p.col(N-1) = -(Xref.col(N-1)^T * Pinf)  (admm.cpp:83): a vectorised reduction over k
+#pragma unroll
+        for (int k = 0; k < NX; k++) PT[k] = gains[(2 * NX + 2 * NU + 1 + k) * 16 + r16];
+        row_products<0, NX>(t, xrN, PT);
+        pterm = -vec_sum(t);
+    }
+    double r_ps = 0, r_pi = 0, r_ds = 0, r_di = 0;
+    {
+        const size_t bi = b;
+        r_ps = P.res[0 * bp + bi]; r_pi = P.res[1 * bp + bi]; r_ds = P.res[2 * bp + bi]; r_di = P.res[3 * bp + bi];
+    }
+    int status = ST_UNSOLVED, itn = 1; // admm.cpp:114-115
+    bool active = valid;
+    double pN = 0.0;
+
+    for (int it = 0; it < P.max_iter; ++it)
+    {
+        if (!__any(active)) break;
+        // No divergent region around the body: a row that has converged keeps executing with its wave and every update of its
+        // state is a select on `active` (a compiler-visible `if (active)` would make hipcc keep the old and the new value of
+        // all 3N state registers alive across the region: 264 spilled registers at N = 30).
+        itn = active ? it + 1 : itn; // admm.cpp:120
+        // the last permitted backward sweep must not overwrite d in c: x, u of an instance that exhausts max_iter come from
+        // the d its last forward sweep used (regenerated below); the final d itself goes to pd
+        const bool keep_d = (it == P.max_iter - 1);
+        // ---- forward_pass + update_slack + update_dual + residual maxima (admm.cpp:27-71, 95-98) ----
+        double s = x0, pri = 0.0, dua = 0.0, t1 = 0.0;
+        double lo[F64_AHEAD], hi[F64_AHEAD];
+        // an offset the compiler cannot see through, renewed every iteration: without it LICM hoists the 2N 64-bit bound
+        // addresses out of the iteration loop and keeps them in 4N registers
+        int oz;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+        const double *const pl = pl0 + oz, *const ph = ph0 + oz;
+        auto ld_bounds = [&](int i, double &l, double &h) {
+            const size_t o = (size_t)((is_u && i >= N - 1) ? 0 : i) * bstep;
+            l = pl[o]; h = ph[o];
+        };
+#pragma unroll
+        for (int k = 0; k < F64_AHEAD; k++) ld_bounds(k < N ? k : N - 1, lo[k], hi[k]);
+#pragma unroll
+        for (int i = 0; i < N; i++)
+        {
+            double sv, xn = 0.0;
+            if (i < N - 1)
+            {
+                double t[NX], t2[NU];
+                row_products<0, NX>(t, s, M1);
+                const double acc = is_x ? lazy_sum<NX>(t) : lazy_sum<NU>(t);   // Adyn*x | Kinf*x
+                const double un = -acc - c[i];                                   // admm.cpp:31
+                row_products<NX, NU>(t2, un, M2);
+                xn = acc + lazy_sum<NX>(t2);                                     // admm.cpp:35
+                sv = is_u ? un : s;
+            }
+            else sv = is_x ? s : 0.0;
+            const double lo_i = lo[i % F64_AHEAD], hi_i = hi[i % F64_AHEAD];
+            if (i + F64_AHEAD < N) ld_bounds(i + F64_AHEAD, lo[i % F64_AHEAD], hi[i % F64_AHEAD]);
+            const double t0 = sv + a[i];                                         // admm.cpp:47-48
+            double tc = t0;
+            if (en_b && (i < N - 1 || is_x))                                     // admm.cpp:51-60: min(max, max(min, t)); u has N - 1 steps
+            {
+                tc = (lo_i < tc) ? tc : lo_i;
+                tc = (tc < hi_i) ? tc : hi_i;
+            }
+            const double an = (a[i] + sv) - tc;                                  // admm.cpp:69-70
+            pri = fmax(pri, fabs(sv - tc));                                      // admm.cpp:95,97
+            dua = fmax(dua, fabs(BB_GET(i) - tc));                               // admm.cpp:96,98
+            a[i] = active ? an : a[i];
+            if constexpr (LDS_SLACK) { if (active) SN_SET(i, tc); }
+            else sn_r[LDS_SLACK ? 0 : i] = active ? tc : sn_r[LDS_SLACK ? 0 : i];
+            t1 = tc - an;
+            s = xn;
+        }
+        pN = active ? pterm - rho * t1 : pN; // admm.cpp:83-84
+        const double pri_x = row_max(is_x ? pri : 0.0), dua_x = row_max(is_x ? dua : 0.0);
+        const double pri_u = row_max(is_u ? pri : 0.0), dua_u = row_max(is_u ? dua : 0.0);
+        bool conv = false;
+        if ((it + 1) % P.check_termination == 0) // admm.cpp:91-109 (wave-uniform condition)
+        {
+            r_ps = active ? pri_x : r_ps; r_ds = active ? dua_x * rho : r_ds; r_pi = active ? pri_u : r_pi; r_di = active ? dua_u * rho : r_di;
+            conv = active && (r_ps < P.abs_pri_tol) && (r_pi < P.abs_pri_tol) && (r_ds < P.abs_dua_tol) && (r_di < P.abs_dua_tol);
+        }
+        status = conv ? ST_SOLVED : status; // admm.cpp:136: returns before the v/z copy and the backward pass
+        active = active && !conv;
+        if (!__any(active)) break;
+        // ---- v = vnew, z = znew (admm.cpp:141-142), update_linear_cost + backward_pass_grad (admm.cpp:15-22, 80-82) ----
+        double p = pN;
+        if constexpr (LDS_SLACK) { if (active) BB_SET(N - 1, SN_GET(N - 1)); }
+        else bb_r[LDS_SLACK ? 0 : N - 1] = active ? sn_r[LDS_SLACK ? 0 : N - 1] : bb_r[LDS_SLACK ? 0 : N - 1];
+#pragma unroll
+        for (int i = N - 2; i >= 0; i--)
+        {
+            const double sni = SN_GET(i);
+            if constexpr (LDS_SLACK) { if (active) BB_SET(i, sni); }
+            else bb_r[LDS_SLACK ? 0 : i] = active ? sni : bb_r[LDS_SLACK ? 0 : i];
+            const double cq = is_x ? c[i] : -0.0; // u rows: r = -rho*(znew - y) keeps the sign of a zero difference
+            const double lin = cq - rho * (sni - a[i]);
+            double t[NX], tk[NU], td[NU];
+            row_products<0, NX>(t, p, M3);
+            // x rows: AmBKt*p (coefficient-evaluated: halving tree, or sequential when nu = 1); u rows: Bdyn^T*p (vectorised reduction)
+            const double dot = is_x ? ((NU == 1 && NX % PS == 0) ? seq_sum(t) : novec_sum(t)) : vec_sum(t);
+            const double wv = lin + dot;               // q + AmBKt*p | Bdyn^T*p + r
+            row_products<NX, NU>(tk, lin, M45);        // Kinf^T * r
+            row_products<NX, NU>(td, wv, M45);         // Quu_inv * (Bdyn^T p + r)
+            const double pn = wv - vec_sum(tk);        // admm.cpp:20
+            const double dd = lazy_sum<NU>(td);        // admm.cpp:19
+            pd[i] = active ? (is_u ? dd : pn) : pd[i];
+            c[i] = (active && is_u && !keep_d) ? dd : c[i];
+            p = pn;
+        }
+    }
+    // ---- live-out: every work array once ----
+    {
+        const bool solved = status == ST_SOLVED;
+        double s = x0;
+#pragma unroll
+        for (int i = 0; i < N; i++)
+        {
+            double sv, xn = 0.0;
+            if (i < N - 1) // x, u regenerated from the d of the last executed forward sweep by the same instruction sequence
+            {
+                double t[NX], t2[NU];
+                row_products<0, NX>(t, s, M1);
+                const double acc = is_x ? lazy_sum<NX>(t) : lazy_sum<NU>(t);
+                const double un = -acc - c[i];
+                row_products<NX, NU>(t2, un, M2);
+                xn = acc + lazy_sum<NX>(t2);
+                sv = is_u ? un : s;
+            }
+            else sv = is_x ? s : 0.0;
+            s = xn;
+            st(TINY_ARR_X, TINY_ARR_U, i, sv);
+            const double sni = SN_GET(i);
+            st(TINY_ARR_Q, TINY_ARR_R, i, (is_x ? c[i] : -0.0) - rho * (sni - a[i]));
+            st(TINY_ARR_P, TINY_ARR_D, i, i == N - 1 ? pN : pd[i]);
+            st(TINY_ARR_V, TINY_ARR_Z, i, BB_GET(i));
+            st(TINY_ARR_VNEW, TINY_ARR_ZNEW, i, sni);
+            st(TINY_ARR_G, TINY_ARR_Y, i, a[i]);
+        }
+        if (valid && r16 == 0)
+        {
+            P.res[0 * bp + inst] = r_ps; P.res[1 * bp + inst] = r_pi; P.res[2 * bp + inst] = r_ds; P.res[3 * bp + inst] = r_di;
+            P.status[inst] = status;
+            P.iter[inst] = itn;
+            if (!solved) atomicAdd(P.n_unsolved, 1);
+        }
+    }
+#undef BB_GET
+#undef SN_GET
+#undef BB_SET
+#undef SN_SET
+}
+
 // host layout [cnt][steps][dim] (cnt = 1: shared, stored once with stride 1)  <->  device [steps][dim][stride]
 __global__ void pack64_kernel(const double *__restrict__ src, double *__restrict__ dst, int nb, int steps, int dim, int stride, int step0, int nsteps)
 {
@@ -362,6 +634,8 @@ struct TinyBatch64
     int in_stride[5] = {1, 1, 1, 1, 1};
     bool in_set[5] = {};
     double *mats = nullptr, *res = nullptr, *staging = nullptr;
+    double *row_gains = nullptr; // [3nx + 2nu + 1 + nx][16]: the matrices as one register per column and lane (admm_f64_rows_kernel)
+    int kernel_choice = 0;       // tiny_batch64_select_kernel: 0 auto, 1 thread per instance, 2 sixteen lanes per instance
     int *status = nullptr, *iter = nullptr, *n_unsolved = nullptr;
     std::vector<double> hm; // host copy of the packed matrices
     bool have_cache = false, have_dyn = false, have_settings = false, mats_dirty = true;
@@ -380,6 +654,43 @@ size_t mat_off(const TinyBatch64 *tb, int which) // Kinf, Pinf, Quu_inv, AmBKt, 
     size_t o = 0;
     for (int k = 0; k < which; k++) o += sz[k];
     return o;
+}
+bool rows_supported(int nx, int nu, int N)
+{
+#define TINY_F64ROWS_CHECK(NX, NU, NN) \
+    if (nx == NX && nu == NU && N == NN) return true;
+    TINY_FOR_EACH_F64ROWS(TINY_F64ROWS_CHECK)
+    return false;
+}
+// lane r of a row holds, per matrix column, the element of the row it owns (x rows r < nx, u rows nx <= r < nx + nu):
+//   M1[k]  x rows Adyn(r,k)   | u rows Kinf(m,k)        M2[m]  x rows Bdyn(r,m)
+//   M3[k]  x rows AmBKt(r,k)  | u rows Bdyn(k,m)        M45[m] x rows Kinf(m,r) | u rows Quu_inv(mr,m)
+//   Q      x rows Q(r)                                  PT[k]  x rows Pinf(k,r)
+std::vector<double> pack_row_gains(const TinyBatch64 *tb)
+{
+    const int nx = tb->nx, nu = tb->nu;
+    const double *K = tb->hm.data() + mat_off(tb, 0), *Pinf = tb->hm.data() + mat_off(tb, 1), *Quu = tb->hm.data() + mat_off(tb, 2),
+                 *Am = tb->hm.data() + mat_off(tb, 3), *A = tb->hm.data() + mat_off(tb, 4), *B = tb->hm.data() + mat_off(tb, 5),
+                 *Q = tb->hm.data() + mat_off(tb, 6);
+    std::vector<double> g((size_t)(3 * nx + 2 * nu + 1) * 16, 0.0);
+    for (int r = 0; r < 16; r++)
+    {
+        const bool isx = r < nx, isu = r >= nx && r < nx + nu;
+        const int mr = r - nx;
+        for (int k = 0; k < nx; k++)
+        {
+            g[(size_t)k * 16 + r] = isx ? A[k * nx + r] : (isu ? K[k * nu + mr] : 0.0);
+            g[(size_t)(nx + nu + k) * 16 + r] = isx ? Am[k * nx + r] : (isu ? B[mr * nx + k] : 0.0);
+            g[(size_t)(2 * nx + 2 * nu + 1 + k) * 16 + r] = isx ? Pinf[r * nx + k] : 0.0;
+        }
+        for (int m = 0; m < nu; m++)
+        {
+            g[(size_t)(nx + m) * 16 + r] = isx ? B[m * nx + r] : 0.0;
+            g[(size_t)(2 * nx + nu + m) * 16 + r] = isx ? K[r * nu + m] : (isu ? Quu[m * nu + mr] : 0.0);
+        }
+        g[(size_t)(2 * nx + 2 * nu) * 16 + r] = isx ? Q[r] : 0.0;
+    }
+    return g;
 }
 int set_input(TinyBatch64 *tb, int which, const double *src, int shared)
 {
@@ -450,7 +761,7 @@ void tiny_batch64_destroy(TinyBatch64 *tb)
     (void)hipSetDevice(tb->device);
     for (int id = 0; id < TINY_ARR_COUNT; id++) (void)hipFree(tb->arr[id]);
     for (int w = 0; w < 5; w++) (void)hipFree(tb->in[w]);
-    (void)hipFree(tb->mats); (void)hipFree(tb->res); (void)hipFree(tb->staging);
+    (void)hipFree(tb->mats); (void)hipFree(tb->res); (void)hipFree(tb->staging); (void)hipFree(tb->row_gains);
     (void)hipFree(tb->status); (void)hipFree(tb->iter); (void)hipFree(tb->n_unsolved);
     delete tb;
 }
@@ -529,8 +840,14 @@ int tiny_batch64_solve(TinyBatch64 *tb)
     if (tb->mats_dirty)
     {
         HIP64(hipMemcpy(tb->mats, tb->hm.data(), tb->hm.size() * sizeof(double), hipMemcpyHostToDevice));
+        const std::vector<double> g = pack_row_gains(tb);
+        if (!tb->row_gains) HIP64(hipMalloc((void **)&tb->row_gains, g.size() * sizeof(double)));
+        HIP64(hipMemcpy(tb->row_gains, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
         tb->mats_dirty = false;
     }
+    const bool rows = tb->kernel_choice == 2 || (tb->kernel_choice == 0 && rows_supported(tb->nx, tb->nu, tb->N));
+    if (rows && !rows_supported(tb->nx, tb->nu, tb->N))
+        return fail64(TINY_BATCH_EUNSUPPORTED, "the sixteen-lane fp64 kernel has no instantiation for nx=%d nu=%d N=%d", tb->nx, tb->nu, tb->N);
     Params64 P;
     P.nx = tb->nx; P.nu = tb->nu; P.N = tb->N; P.batch = tb->batch; P.bpad = tb->bpad;
     P.rho = tb->rho; P.abs_pri_tol = tb->abs_pri_tol; P.abs_dua_tol = tb->abs_dua_tol;
@@ -542,13 +859,41 @@ int tiny_batch64_solve(TinyBatch64 *tb)
     P.mats = tb->mats; P.res = tb->res; P.status = tb->status; P.iter = tb->iter; P.n_unsolved = tb->n_unsolved;
     HIP64(hipMemset(tb->n_unsolved, 0, sizeof(int)));
     const int nblocks = tb->bpad / WAVE64;
-    if (tb->nx == 12 && tb->nu == 4) hipLaunchKernelGGL((admm_f64_kernel<12, 4>), dim3(nblocks), dim3(WAVE64), 0, 0, P);
+    if (rows)
+    {
+        const int nrow_blocks = (tb->batch + 3) / 4;
+#define TINY_F64ROWS_LAUNCH(NX, NU, NN)                                                                                            \
+    if (tb->nx == NX && tb->nu == NU && tb->N == NN)                                                                               \
+        hipLaunchKernelGGL((admm_f64_rows_kernel<NX, NU, NN>), dim3(nrow_blocks), dim3(WAVE64), 0, 0, P, (const double *)tb->row_gains);
+        TINY_FOR_EACH_F64ROWS(TINY_F64ROWS_LAUNCH)
+    }
+    else if (tb->nx == 12 && tb->nu == 4) hipLaunchKernelGGL((admm_f64_kernel<12, 4>), dim3(nblocks), dim3(WAVE64), 0, 0, P);
     else if (tb->nx == 4 && tb->nu == 1) hipLaunchKernelGGL((admm_f64_kernel<4, 1>), dim3(nblocks), dim3(WAVE64), 0, 0, P);
     else hipLaunchKernelGGL((admm_f64_kernel<8, 4>), dim3(nblocks), dim3(WAVE64), 0, 0, P);
     HIP64(hipGetLastError());
     int n = 0;
     HIP64(hipMemcpy(&n, tb->n_unsolved, sizeof(int), hipMemcpyDeviceToHost));
     return n > 0 ? 1 : 0;
+}
+
+int tiny_batch64_select_kernel(TinyBatch64 *tb, int which)
+{
+    CHECK64(tb, "NULL handle");
+    CHECK64(which >= 0 && which <= 2, "kernel must be 0 (auto), 1 (one thread per instance) or 2 (sixteen lanes per instance)");
+    if (which == 2 && !rows_supported(tb->nx, tb->nu, tb->N))
+        return fail64(TINY_BATCH_EUNSUPPORTED, "the sixteen-lane fp64 kernel has no instantiation for nx=%d nu=%d N=%d", tb->nx, tb->nu, tb->N);
+    tb->kernel_choice = which;
+    return 0;
+}
+
+const char *tiny_batch64_kernel_name(TinyBatch64 *tb)
+{
+    static thread_local char nm[64];
+    if (!tb) return "";
+    const bool rows = tb->kernel_choice == 2 || (tb->kernel_choice == 0 && rows_supported(tb->nx, tb->nu, tb->N));
+    if (rows) snprintf(nm, sizeof nm, "rows64<%d,%d,%d>", tb->nx, tb->nu, tb->N);
+    else snprintf(nm, sizeof nm, "thread64<%d,%d>", tb->nx, tb->nu);
+    return nm;
 }
 
 int tiny_batch64_set_array(TinyBatch64 *tb, int id, const double *src)

@@ -94,12 +94,14 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch64_reset_dual_variables": [P], "tiny_batch64_solve": [P],
         "tiny_batch64_set_array": [P, C.c_int, D], "tiny_batch64_get_array": [P, C.c_int, D],
         "tiny_batch64_get_status": [P, I, I, D], "tiny_batch64_set_status": [P, I, I, D],
+        "tiny_batch64_select_kernel": [P, C.c_int],
     }
     for name, args in sig64.items():
         fn = getattr(lib, name)
         fn.argtypes, fn.restype = args, C.c_int
     lib.tiny_batch64_destroy.argtypes, lib.tiny_batch64_destroy.restype = [P], None
     lib.tiny_batch64_last_error.argtypes, lib.tiny_batch64_last_error.restype = [], C.c_char_p
+    lib.tiny_batch64_kernel_name.argtypes, lib.tiny_batch64_kernel_name.restype = [P], C.c_char_p
     lib.tiny_batch_destroy.argtypes, lib.tiny_batch_destroy.restype = [P], None
     lib.tiny_batch_last_error.argtypes, lib.tiny_batch_last_error.restype = [], C.c_char_p
     lib.tiny_batch_kernel_name.argtypes, lib.tiny_batch_kernel_name.restype = [P], C.c_char_p
@@ -458,6 +460,12 @@ class TinyBatchSolver64:
         self._set_steps(self.lib.tiny_batch64_set_umax, u_max, self.N - 1, self.nu)
 
     def reset_dual_variables(self): self._check(self.lib.tiny_batch64_reset_dual_variables(self._h))
+
+    def select_kernel(self, which: int):
+        """0 = automatic, 1 = one thread per instance (state in HBM, any N), 2 = sixteen lanes per instance (state in registers)."""
+        self._check(self.lib.tiny_batch64_select_kernel(self._h, which))
+
+    def kernel_name(self) -> str: return self.lib.tiny_batch64_kernel_name(self._h).decode()
 
     def solve(self) -> int: return self._check(self.lib.tiny_batch64_solve(self._h))
 

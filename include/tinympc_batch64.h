@@ -14,8 +14,9 @@
  * work arrays, the residuals, status, iter).
  *
  * Scope: tiny_solve and the wrapper-style accessors.  Problem classes with a compiled instantiation: (nx, nu) =
- * (12, 4), (4, 1), (8, 4), any horizon N.  One thread per instance, state in HBM (fp64 halves the register budget of the
- * state-on-chip kernels; the double path is the reference's desktop configuration, not the throughput path).
+ * (12, 4), (4, 1), (8, 4), any horizon N.  Two kernels with identical results: sixteen lanes per instance with the state in
+ * registers for the whole solve (instantiated horizons, the default where one exists) and one thread per instance with the
+ * state in HBM (any N).
  */
 #ifndef TINYMPC_BATCH64_H
 #define TINYMPC_BATCH64_H
@@ -52,6 +53,12 @@ extern "C"
     int tiny_batch64_reset_dual_variables(TinyBatch64 *tb);                     /* y = 0, g = 0 (tiny_wrapper.cpp:131) */
     /* tiny_solve() for every instance (admm.cpp:111-152): 0 = all converged, 1 = some hit max_iter, < 0 = error */
     int tiny_batch64_solve(TinyBatch64 *tb);
+
+    /* Implementation: 0 = automatic (the second where (nx, nu, N) has an instantiation, else the first), 1 = one thread per
+     * instance with the state in HBM (any N), 2 = sixteen lanes per instance with the state in registers for the whole solve
+     * (instantiated (nx, nu, N): (12,4,10) as shipped, (12,4,20), (12,4,30), (4,1,10), (8,4,9)).  Identical results. */
+    int tiny_batch64_select_kernel(TinyBatch64 *tb, int which);
+    const char *tiny_batch64_kernel_name(TinyBatch64 *tb);
 
     /* whole workspace, ids of TinyBatchArray */
     int tiny_batch64_set_array(TinyBatch64 *tb, int id, const double *src);

@@ -20,7 +20,7 @@ from oracle import oracle as O  # noqa: E402
 pr = T.problems
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-CLASSES = [("quad", 10), ("quad", 30), ("quad", 7), ("quad", 41), ("cartpole", 10), ("cartpole", 3), ("cartpole", 33), ("r8_4", 9), ("r8_4", 26)]
+CLASSES = [("quad", 10), ("quad", 30), ("quad", 20), ("quad", 7), ("quad", 41), ("cartpole", 10), ("cartpole", 3), ("cartpole", 33), ("r8_4", 9), ("r8_4", 26)]
 t_end, rounds, solves, t_note, overflowed = time.time() + budget, 0, 0, time.time(), 0
 while time.time() < t_end:
     if time.time() - t_note > 45:
@@ -44,6 +44,8 @@ while time.time() < t_end:
     if rng.random() < 0.3:
         bnds = tuple(a[None] * rng.uniform(0.3, 1.0, size=(B,) + a.shape) for a in bnds)
     sol = T.TinyBatchSolver64(prob, B, settings=settings)
+    if rng.random() < 0.4:
+        sol.select_kernel(1)   # one thread per instance; otherwise automatic (sixteen lanes per instance where instantiated)
     sol.set_bounds(*bnds)
     xref = rng.standard_normal((N, nx) if rng.random() < 0.5 else (B, N, nx)) * 0.3
     sol.set_xref(xref)
@@ -79,7 +81,7 @@ while time.time() < t_end:
             else:
                 same = np.array_equal(g_, r_)
             if not same:
-                print(f"MISMATCH round {rounds} {kind} N={N} B={B} settings {settings} per-instance bounds {bnds[0].ndim == 3} xref {xref.shape} solve {k}: {name}")
+                print(f"MISMATCH round {rounds} {kind} N={N} B={B} kernel {sol.kernel_name()} settings {settings} per-instance bounds {bnds[0].ndim == 3} xref {xref.shape} solve {k}: {name}")
                 bad = np.argwhere(~((g_ == r_) & (np.signbit(g_) == np.signbit(r_)))) if g_.dtype.kind == "f" else np.argwhere(g_ != r_)
                 for idx in bad[:6]:
                     idx = tuple(idx)

@@ -1896,17 +1896,22 @@ def test_per_instance_bounds_stay_on_the_register_resident_kernel_and_cost_littl
 # ---------------------------------------------------------------------------------------------------------------------
 # tinytype = double (the reference as shipped, glob_opts.hpp:3): include/tinympc_batch64.h
 # ---------------------------------------------------------------------------------------------------------------------
-def test_fp64_as_shipped_hovering_loop_and_golden_vectors(tinympc, oracle_mod):
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_fp64_as_shipped_hovering_loop_and_golden_vectors(tinympc, oracle_mod, kernel):
     """The reference exactly as checked in — typedef double tinytype, NSTATES 12, NINPUTS 4, NHORIZON 10 (glob_opts.hpp:3-7),
     examples/quadrotor_hovering.cpp — through the fp64 library: the recorded solves (k = 0 and k = 69) reproduce all twelve
     work arrays, residuals, status and iter of the compiled reference bit for bit, and the whole 70-step closed loop reproduces
-    its controls and iteration counts (SURVEY.md §4 KATs: 1269 iterations, u0 = 0.488778532 ...)."""
+    its controls and iteration counts (SURVEY.md §4 KATs: 1269 iterations, u0 = 0.488778532 ...).  Both kernels: one thread
+    per instance with the state in HBM (1), sixteen lanes per instance with the state in registers (2, the default here)."""
     O = oracle_mod
     meta, prob, solves, z = load_fixture("quad_hover_f64_N10")
     assert meta["dtype"] == "float64" and prob["N"] == 10
     bnds = bounds_of(prob, np.float64)
     for s in solves:
         sol = tinympc.TinyBatchSolver64(prob, 1, settings=s["settings"])
+        assert sol.kernel_name() == "rows64<12,4,10>", sol.kernel_name()   # the automatic choice
+        sol.select_kernel(kernel)
+        assert sol.kernel_name() == ("thread64<12,4>" if kernel == 1 else "rows64<12,4,10>")
         sol.set_bounds(*bnds); sol.set_xref(s["xref"])
         sol.set_state(s["pre"])
         rc = sol.solve()
@@ -1914,6 +1919,7 @@ def test_fp64_as_shipped_hovering_loop_and_golden_vectors(tinympc, oracle_mod):
         assert_bitwise(sol.get_state(), s["post"], f"fp64 golden solve k={s['k']}")
         sol.close()
     sol = tinympc.TinyBatchSolver64(prob, 1, settings=solves[0]["settings"])
+    sol.select_kernel(kernel)
     sol.set_bounds(*bnds); sol.set_xref(solves[0]["xref"])
     sol.set_state(solves[0]["pre"])
     orc = O.Oracle(prob, np.float64)
@@ -1932,8 +1938,9 @@ def test_fp64_as_shipped_hovering_loop_and_golden_vectors(tinympc, oracle_mod):
     sol.close()
 
 
-@pytest.mark.parametrize("nx,nu,N", [(12, 4, 30), (12, 4, 10), (4, 1, 10), (8, 4, 9)])
-def test_fp64_vs_oracle(tinympc, oracle_mod, nx, nu, N):
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("nx,nu,N", [(12, 4, 30), (12, 4, 10), (12, 4, 20), (4, 1, 10), (8, 4, 9), (12, 4, 13)])
+def test_fp64_vs_oracle(tinympc, oracle_mod, nx, nu, N, kernel):
     """The fp64 library against the fp64 oracle (== the compiled reference's fp64 builds, tests/test_oracle.py) on random
     warm states with zeros and negative zeros: ragged batches, warm-started chain with dual resets, sparse termination
     checks, max_iter 0 / 1, bounds off, per-instance bounds and references.  Bitwise, signs of zeros included."""
@@ -1955,13 +1962,20 @@ def test_fp64_vs_oracle(tinympc, oracle_mod, nx, nu, N):
             st[k][rng.random(st[k].shape) < 0.1] = 0.0
             st[k][rng.random(st[k].shape) < 0.1] = -0.0
         st["residuals"][:] = rng.random((B, 4)); st["iter"][:] = 3; st["status"][:] = 11
-        shared = pr.bounds_arrays(prob, np.float64)
+        shared = tuple(np.array(v, np.float64) for v in pr.bounds_arrays(prob, np.float64))
+        shared[2][0, 0] = 0.2 * shared[3][0, 0]   # a lower input bound above zero at step 0 (the nonexistent u step N-1 must not see it)
         if per_inst:
             bnds = tuple(a[None] * rng.uniform(0.1, 1.0, size=(B,) + a.shape) for a in shared)
             xref = rng.standard_normal((B, N, nx)) * 0.2
         else:
             bnds, xref = shared, rng.standard_normal((N, nx)) * 0.2
         sol = tinympc.TinyBatchSolver64(prob, B, settings=settings)
+        if kernel == 2 and N == 13:   # no sixteen-lane instantiation for this horizon: refused, the thread kernel serves it
+            with pytest.raises(tinympc.TinyBatchError):
+                sol.select_kernel(2)
+            assert sol.kernel_name() == "thread64<12,4>"
+        else:
+            sol.select_kernel(kernel)
         sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_state(st)
         orc = O.Oracle(prob, np.float64, settings)
         for k in range(3):
