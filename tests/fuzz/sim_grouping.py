@@ -2,12 +2,12 @@
 """Developer aid (drives the oracle: test infrastructure, CPU only): replay the iteration counts of the headline workload
 (65 536 tracking instances) through an in-order wave dispatcher to price lock-step loss (a wave runs as long as the slowest
 of its G instances) and the launch tail, for index order, longest-first by true counts, and orders / regroupings derived
-from the residuals after 1-3 iterations (what the on-device predictor sees).   python tools/sim_grouping.py [G] [slots]
+from the residuals after 1-3 iterations (what the on-device predictor sees).   python tests/fuzz/sim_grouping.py [G] [slots]
 G = 4, slots = 2048 is the 16-lane kernel at two waves per SIMD; G = 16, slots = 1024 the 16-instances-per-wave kernel."""
 import sys, heapq
 from pathlib import Path
 import numpy as np
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import accelerated_tinympc_amd as T
 from oracle import oracle as O
 
