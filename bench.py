@@ -18,7 +18,8 @@ data-path collective — torch.distributed is used only for the barriers and the
 
 Prints ONE JSON line (rank 0).  `roofline` and `cpu_baseline` are described in DESIGN.md §Measurement.  At N=1 the line
 also carries extras that never enter `value`: `fast_arithmetic` (the fma variant of the kernel), `closed_loop` (warm-started
-MPC steps in one launch), `pipelined_batches` (consecutive batches double-buffered on two streams).
+MPC steps in one launch), `pipelined_batches` (consecutive batches double-buffered on two streams), `fp64_tinytype` (the
+same workload through the `typedef double tinytype` library).
 """
 from __future__ import annotations
 
@@ -354,6 +355,32 @@ def main():
         for s2 in sols:
             s2.close()
 
+    # The reference as shipped is `typedef double tinytype` (glob_opts.hpp:3): the same workload through the fp64 library
+    # (include/tinympc_batch64.h; results bitwise equal to the reference's fp64 build).  An extra; never part of `value`.
+    fp64 = None
+    if extras_ok and not args.no_closed_loop and args.config == "tracking":
+        try:
+            s64 = T.TinyBatchSolver64(prob, B, device=dev_index, settings=settings)
+            s64.set_bounds(*[np.asarray(a, np.float64) for a in pr.bounds_arrays(prob)])
+            s64.set_xref(pr.expand_windows(table, gstart[lo:hi], N).astype(np.float64))
+            zero = {k: np.zeros_like(v) for k, v in s64.get_state().items() if k not in ("iter", "status", "residuals")}
+            x064 = x0.astype(np.float64)
+            ts = []
+            for _ in range(3):
+                for k, v in zero.items():
+                    s64.set_array(k, v)
+                s64.set_x0(x064)
+                t_6 = time.perf_counter()
+                s64.solve()
+                ts.append(time.perf_counter() - t_6)
+            it6, st6, _ = s64.get_status()
+            fp64 = {"kernel": s64.kernel_name(), "ms_per_solve_call": min(ts[1:]) * 1e3, "solves_per_s": B / min(ts[1:]),
+                    "mean_iters": float(it6.mean()), "frac_converged": float(np.mean(st6 == 1)),
+                    "note": "cold-start tiny_solve of the same instances in double; wall time of the blocking call"}
+            s64.close()
+        except Exception as e:  # noqa: BLE001
+            fp64 = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
         fl = cost.flops_of(iters, status)  # this rank's launch
@@ -427,6 +454,8 @@ def main():
             line["closed_loop"] = closed
         if pipelined is not None:
             line["pipelined_batches"] = pipelined
+        if fp64 is not None:
+            line["fp64_tinytype"] = fp64
         if not args.no_cpu and world == 1:  # rank 0 at N=1 only: the other ranks of a multi-GPU run would sit in the barrier
             cb, ref_first, kind = cpu_baseline(prob, make_batch)
             line["cpu_baseline"] = cb
