@@ -169,14 +169,18 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # rehearsal knobs (one-GPU box): TINYMPC_BENCH_DEVICE pins every rank to one device, TINYMPC_BENCH_BACKEND=gloo
-    # replaces RCCL (two ranks cannot share a GPU under RCCL).  The driver's real runs use neither.
+    # replaces RCCL (two ranks cannot share a GPU under RCCL), TINYMPC_BENCH_FORCE_DIST=1 creates the process group even
+    # for a single rank, so that the RCCL branch itself (init with device_id, barriers, the stats all-reduce and the final
+    # all-gather on device tensors) runs on one GPU.  The driver's real runs use none of them.
     dev_index = int(os.environ.get("TINYMPC_BENCH_DEVICE", local_rank))
     backend = os.environ.get("TINYMPC_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("TINYMPC_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
@@ -438,7 +442,7 @@ def main():
             "config": {"workload": f"{what} batched {B} instances per GPU, cold-start tiny_solve, "
                                    + (f"{args.mode} (tol 1e-3, max_iter 100)" if args.mode == "early_exit" else "fixed 10 iterations"),
                        "nx": NX, "nu": NU, "N": N, "instances_per_gpu": B, "instances_total": total, "parallelism": f"batch-shard x{world}",
-                       "world_size_seen": world_seen, "backend": (backend if world > 1 else "none (single process)"),
+                       "world_size_seen": world_seen, "backend": (backend if dist is not None else "none (single process)"),
                        "kernel": sol.kernel_name(),
                        "dispatch": ("longest first by predicted iteration count (predictor sweep + sort inside the timed region)"
                                     if args.dispatch and sol.kernel_name().startswith(("rowlane", "rowloop")) and B >= 16384 else "index order"),

@@ -98,6 +98,28 @@ def test_bench_two_rank_rehearsal(tmp_path):
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
 
 
+@pytest.mark.gpu
+def test_bench_rccl_branch_single_rank(tmp_path):
+    """The RCCL branch of bench.py itself — process group on the `nccl` backend bound to the device, barriers, the stats
+    all-reduce and the final all-gather on device tensors — rehearsed with ONE rank on one GPU (two ranks cannot share a
+    device under RCCL).  What the driver's N > 1 launch adds on top is more ranks of the same code."""
+    import json
+    env = dict(os.environ, TINYMPC_BENCH_FORCE_DIST="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TINYMPC_BENCH_BACKEND", "TINYMPC_BENCH_DEVICE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "8192",
+           "--no-cpu", "--no-closed-loop"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["world_size_seen"] == 1 and d["config"]["backend"] == "nccl"
+    assert d["final_gather"]["own_block_intact"] is True, d["final_gather"]
+    assert d["config"]["frac_converged"] == 1.0 and d["value"] > 1e6
+
+
 def test_two_gloo_ranks_match_single_process(tmp_path, oracle_mod, tinympc):
     _run_two_ranks(tmp_path, oracle_mod, tinympc, "oracle")
 
