@@ -597,6 +597,42 @@ __global__ void unpack64_kernel(const double *__restrict__ src, double *__restri
     }
 }
 
+// Plant step of the examples' closed loop (quadrotor_hovering.cpp:110-111): x.col(0) <- Adyn * x.col(0) + Bdyn * u.col(0), in
+// Eigen's order for that expression over tiny_VectorNx: a product whose rows and depth are both >= 8 runs through the
+// column-major GEMV kernel (row accumulator from +0, then alpha * acc + result), anything smaller is the lazy product's
+// sequential sum (tests/test_oracle.py: test_plant_step_bit_exact_vs_compiled_reference pins the oracle's restatement of
+// this against the compiled expression, fp64 configurations included).
+template <int NX, int NU>
+__global__ void plant64_kernel(double *__restrict__ X, const double *__restrict__ U, const double *__restrict__ mats, int batch, int bpad)
+{
+    static_assert(!(NX >= 8 && NU >= 8), "Bdyn*u would take the GEMV kernel too");
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    constexpr int OFF_A = NU * NX + NX * NX + NU * NU + NX * NX, OFF_B = OFF_A + NX * NX;
+    const double *A = mats + OFF_A, *Bm = mats + OFF_B;
+    double x[NX], u[NU], xn[NX];
+#pragma unroll
+    for (int j = 0; j < NX; j++) x[j] = X[(size_t)j * bpad + b];
+#pragma unroll
+    for (int j = 0; j < NU; j++) u[j] = U[(size_t)j * bpad + b];
+#pragma unroll
+    for (int i = 0; i < NX; i++)
+    {
+        double a;
+        if constexpr (NX >= 8)
+        {
+            double c = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; j++) c = A[j * NX + i] * x[j] + c;
+            a = c * 1.0 + 0.0;
+        }
+        else a = row_dot<NX, NX>(A, i, x);
+        xn[i] = a + row_dot<NX, NU>(Bm, i, u);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; i++) X[(size_t)i * bpad + b] = xn[i];
+}
+
 thread_local std::string g_err64;
 int fail64(int code, const char *fmt, ...)
 {
@@ -874,6 +910,38 @@ int tiny_batch64_solve(TinyBatch64 *tb)
     int n = 0;
     HIP64(hipMemcpy(&n, tb->n_unsolved, sizeof(int), hipMemcpyDeviceToHost));
     return n > 0 ? 1 : 0;
+}
+
+int tiny_batch64_mpc_step(TinyBatch64 *tb)
+{
+    CHECK64(tb, "NULL handle");
+    int rc = tiny_batch64_reset_dual_variables(tb); // quadrotor_hovering.cpp:100-101
+    if (rc < 0) return rc;
+    rc = tiny_batch64_solve(tb);                    // :104
+    if (rc < 0) return rc;
+    const int nb = (tb->batch + 127) / 128;          // :110-111
+    if (tb->nx == 12 && tb->nu == 4) hipLaunchKernelGGL((plant64_kernel<12, 4>), dim3(nb), dim3(128), 0, 0, tb->arr[TINY_ARR_X], tb->arr[TINY_ARR_U], tb->mats, tb->batch, tb->bpad);
+    else if (tb->nx == 4 && tb->nu == 1) hipLaunchKernelGGL((plant64_kernel<4, 1>), dim3(nb), dim3(128), 0, 0, tb->arr[TINY_ARR_X], tb->arr[TINY_ARR_U], tb->mats, tb->batch, tb->bpad);
+    else hipLaunchKernelGGL((plant64_kernel<8, 4>), dim3(nb), dim3(128), 0, 0, tb->arr[TINY_ARR_X], tb->arr[TINY_ARR_U], tb->mats, tb->batch, tb->bpad);
+    HIP64(hipGetLastError());
+    return rc;
+}
+
+int tiny_batch64_get_first_columns(TinyBatch64 *tb, double *x0, double *u0)
+{
+    CHECK64(tb, "NULL handle");
+    HIP64(hipSetDevice(tb->device));
+    for (int w = 0; w < 2; w++)
+    {
+        double *dst = w ? u0 : x0;
+        if (!dst) continue;
+        const int dim = w ? tb->nu : tb->nx;
+        hipLaunchKernelGGL(unpack64_kernel, dim3(grid64((long long)tb->batch * dim)), dim3(256), 0, 0, tb->arr[w ? TINY_ARR_U : TINY_ARR_X], tb->staging,
+                           tb->batch, 1, dim, tb->bpad);
+        HIP64(hipGetLastError());
+        HIP64(hipMemcpy(dst, tb->staging, (size_t)tb->batch * dim * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return 0;
 }
 
 int tiny_batch64_select_kernel(TinyBatch64 *tb, int which)

@@ -94,7 +94,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch64_reset_dual_variables": [P], "tiny_batch64_solve": [P],
         "tiny_batch64_set_array": [P, C.c_int, D], "tiny_batch64_get_array": [P, C.c_int, D],
         "tiny_batch64_get_status": [P, I, I, D], "tiny_batch64_set_status": [P, I, I, D],
-        "tiny_batch64_select_kernel": [P, C.c_int],
+        "tiny_batch64_select_kernel": [P, C.c_int], "tiny_batch64_mpc_step": [P], "tiny_batch64_get_first_columns": [P, D, D],
     }
     for name, args in sig64.items():
         fn = getattr(lib, name)
@@ -466,6 +466,16 @@ class TinyBatchSolver64:
         self._check(self.lib.tiny_batch64_select_kernel(self._h, which))
 
     def kernel_name(self) -> str: return self.lib.tiny_batch64_kernel_name(self._h).decode()
+
+    def mpc_step(self) -> int:
+        """y = g = 0, tiny_solve, x.col(0) <- Adyn x.col(0) + Bdyn u.col(0) (quadrotor_hovering.cpp:95-111), on the device."""
+        return self._check(self.lib.tiny_batch64_mpc_step(self._h))
+
+    def first_columns(self):
+        """(x.col(0), u.col(0)) as [B][nx], [B][nu]."""
+        x0, u0 = np.empty((self.B, self.nx)), np.empty((self.B, self.nu))
+        self._check(self.lib.tiny_batch64_get_first_columns(self._h, self._dp(x0), self._dp(u0)))
+        return x0, u0
 
     def solve(self) -> int: return self._check(self.lib.tiny_batch64_solve(self._h))
 

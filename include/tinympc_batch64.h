@@ -54,6 +54,13 @@ extern "C"
     /* tiny_solve() for every instance (admm.cpp:111-152): 0 = all converged, 1 = some hit max_iter, < 0 = error */
     int tiny_batch64_solve(TinyBatch64 *tb);
 
+    /* One step of the examples' closed loop (quadrotor_hovering.cpp:95-111) on the device: y = g = 0, tiny_solve, then the plant
+     * update x.col(0) <- Adyn * x.col(0) + Bdyn * u.col(0) in the order Eigen evaluates that expression (bitwise equal to
+     * the compiled example).  Returns what tiny_batch64_solve returns.  tiny_batch64_get_first_columns reads x.col(0) (after the
+     * plant update: the next x0) and u.col(0) (the control just computed) without moving the whole horizon; either may be NULL. */
+    int tiny_batch64_mpc_step(TinyBatch64 *tb);
+    int tiny_batch64_get_first_columns(TinyBatch64 *tb, double *x0, double *u0);
+
     /* Implementation: 0 = automatic (the second where (nx, nu, N) has an instantiation, else the first), 1 = one thread per
      * instance with the state in HBM (any N), 2 = sixteen lanes per instance with the state in registers for the whole solve
      * (instantiated (nx, nu, N): (12,4,10) as shipped, (12,4,20), (12,4,30), (4,1,10), (8,4,9)).  Identical results. */

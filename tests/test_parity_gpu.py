@@ -1935,6 +1935,44 @@ def test_fp64_as_shipped_hovering_loop_and_golden_vectors(tinympc, oracle_mod, k
     assert np.array_equal(np.array(iters), z["trace_iter"]) and np.array_equal(np.array(u0s), z["trace_u0"])
     assert sum(iters) == 1269 and iters[0] == 100 and iters[69] == 2
     np.testing.assert_allclose(u0s[0], [0.488778532, 0.478938215, 0.542743696, 0.551056731], rtol=0, atol=5e-10)
+    # the same loop with the plant update on the device (tiny_batch64_mpc_step): identical trace, identical next x0
+    sol.set_state(solves[0]["pre"])
+    it2, u2 = [], []
+    for k in range(70):
+        sol.mpc_step()
+        xk, uk = sol.first_columns()
+        it2.append(int(sol.get_status()[0][0])); u2.append(uk[0].copy())
+    assert np.array_equal(np.array(it2), z["trace_iter"]) and np.array_equal(np.array(u2), z["trace_u0"])
+    assert np.array_equal(xk, np.reshape(x0, xk.shape)) and np.array_equal(np.signbit(xk), np.signbit(np.reshape(x0, xk.shape)))
+    sol.close()
+
+
+@pytest.mark.parametrize("nx,nu,N", [(4, 1, 10), (8, 4, 9), (12, 4, 30)])
+def test_fp64_device_closed_loop_vs_oracle(tinympc, oracle_mod, nx, nu, N):
+    """tiny_batch64_mpc_step over a batch: 12 closed-loop steps equal the oracle's solve + its plant step (pinned against the
+    compiled Eigen expression, tests/test_oracle.py) bit for bit — the sequential order for nx < 8, the GEMV order for nx >= 8."""
+    O, pr = oracle_mod, tinympc.problems
+    prob = pr.quadrotor(20, N) if (nx, nu) == (12, 4) else (pr.cartpole(N, riccati=O.riccati) if nx == 4 else pr.random_system(nx, nu, N, seed=804, riccati=O.riccati))
+    B = 37
+    rng = np.random.default_rng(N)
+    x0 = rng.uniform(-0.2, 0.2, size=(B, nx))
+    xref = rng.standard_normal((N, nx)) * 0.05
+    bnds = pr.bounds_arrays(prob, np.float64)
+    settings = dict(O.DEFAULT_SETTINGS, max_iter=40)
+    sol = tinympc.TinyBatchSolver64(prob, B, settings=settings)
+    sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
+    orc = O.Oracle(prob, np.float64, settings)
+    st = O.new_state(B, nx, nu, N, np.float64); st["x"][:, 0] = x0
+    for k in range(12):
+        st["y"][:] = 0; st["g"][:] = 0
+        orc.solve(st, *bnds, xref, nthreads=8)
+        u0 = st["u"][:, 0].copy()
+        xn = orc.plant_step(st["x"][:, 0].copy(), u0)
+        sol.mpc_step()
+        xg, ug = sol.first_columns()
+        assert np.array_equal(ug, u0) and np.array_equal(xg, xn) and np.array_equal(np.signbit(xg), np.signbit(xn)), f"step {k}"
+        assert np.array_equal(sol.get_status()[0], st["iter"])
+        st["x"][:, 0] = xn
     sol.close()
 
 
