@@ -16,6 +16,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libtinympc_hip.so"
 WRAPPER_LIB = PKG / "lib" / "libtinympc_wrapper.so"  # same-name twin of the reference's generated wrapper library
+WRAPPER64_LIB = PKG / "lib" / "libtinympc_wrapper64.so"  # the native names (tiny_solve, forward_pass, ...) for tinytype = double
 SOURCES = ["tinympc_batch.hip", "tinympc_batch64.hip", "admm_stream.hip", "admm_rowlane.hip", "admm_rowloop.hip", "admm_quadlane.hip", "admm_tile16.hip", "admm_wave.hip", "admm_waveres.hip", "admm_steps.hip", "dispatch_order.hip", "riccati.cpp"]
 WRAPPER_SRCS = [CSRC / "wrapper_compat.cpp", CSRC / "admm_compat.cpp"]
 HEADERS = [CSRC / "tinympc_internal.h", CSRC / "rowlane_math.h", CSRC / "tile_math.h", CSRC / "wave_math.h", CSRC / "dpp_ops_gen.h", PKG.parent / "include" / "tinympc_batch.h", PKG.parent / "include" / "tinympc_batch64.h"]
@@ -34,9 +35,9 @@ def _objs():
 
 
 def needs_build() -> bool:
-    if not LIB.exists() or not WRAPPER_LIB.exists():
+    if not LIB.exists() or not WRAPPER_LIB.exists() or not WRAPPER64_LIB.exists():
         return True
-    t = min(LIB.stat().st_mtime, WRAPPER_LIB.stat().st_mtime)
+    t = min(LIB.stat().st_mtime, WRAPPER_LIB.stat().st_mtime, WRAPPER64_LIB.stat().st_mtime)
     inc = PKG.parent / "include"
     deps = [s for s, _ in _objs()] + HEADERS + [Path(__file__), *WRAPPER_SRCS, inc / "tinympc_wrapper.h", inc / "tinympc_admm.h", inc / "tinympc_batch.h"]
     return any(d.stat().st_mtime > t for d in deps if d.exists())
@@ -66,6 +67,12 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     # libtinympc_wrapper.so: plain host C++ on top of the C-ABI, finds libtinympc_hip.so next to itself
     cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", str(WRAPPER_LIB), *[str(w) for w in WRAPPER_SRCS], f"-L{LIB.parent}",
            "-ltinympc_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    # libtinympc_wrapper64.so: the native names over TinySolver with double members (include/tinympc_admm.h, TINYMPC_TINYTYPE_DOUBLE)
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DTINYMPC_TINYTYPE_DOUBLE", "-o", str(WRAPPER64_LIB), str(CSRC / "admm_compat.cpp"),
+           f"-L{LIB.parent}", "-ltinympc_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

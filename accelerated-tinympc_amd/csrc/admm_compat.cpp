@@ -2,8 +2,21 @@
 // own names over plain-array structs (include/tinympc_admm.h), for one instance, on top of the batched HIP solver.
 // Part of libtinympc_wrapper.so.  Every call: copy the live-in members to a batch-of-one device workspace, launch the
 // kernel, copy back what the reference function writes.  No CPU arithmetic happens here.
+//
+// Compiled twice: as is for `typedef float tinytype` (what the reference's code generator emits, codegen.cpp:152) into
+// libtinympc_wrapper.so, and with -DTINYMPC_TINYTYPE_DOUBLE for `typedef double tinytype` (the reference as checked in,
+// glob_opts.hpp:3) into libtinympc_wrapper64.so, on top of the fp64 library (include/tinympc_batch64.h).
 #include "../../include/tinympc_admm.h"
 #include "../../include/tinympc_batch.h"
+#ifdef TINYMPC_TINYTYPE_DOUBLE
+#include "../../include/tinympc_batch64.h"
+#define TB(name) tiny_batch64_##name
+typedef TinyBatch64 Handle;
+#else
+#define TB(name) tiny_batch_##name
+typedef TinyBatch Handle;
+#endif
+typedef tinytype real;
 
 #include <cstdio>
 #include <cstring>
@@ -14,11 +27,11 @@ namespace
 
 struct Ctx
 {
-    TinyBatch *tb = nullptr;
+    Handle *tb = nullptr;
     int nx = 0, nu = 0, N = 0, device = 0;
     // last uploaded problem class / inputs, to skip unchanged uploads
-    std::vector<float> gains, bnd[4], xref, opt;
-    float rho = 0.f;
+    std::vector<real> gains, bnd[4], xref, opt;
+    real rho = 0;
 };
 Ctx g_ctx;
 int g_device = 0;
@@ -28,11 +41,11 @@ int g_code = 0;
 int report(const char *what, int rc)
 {
     g_code = rc < 0 ? rc : 0;
-    if (rc < 0) std::fprintf(stderr, "tinympc: %s failed (%d): %s\n", what, rc, tiny_batch_last_error());
+    if (rc < 0) std::fprintf(stderr, "tinympc: %s failed (%d): %s\n", what, rc, TB(last_error)());
     return rc;
 }
 
-bool same(const std::vector<float> &a, const float *b, size_t n) { return a.size() == n && std::memcmp(a.data(), b, n * sizeof(float)) == 0; }
+bool same(const std::vector<real> &a, const real *b, size_t n) { return a.size() == n && std::memcmp(a.data(), b, n * sizeof(real)) == 0; }
 
 #define TRYRC(e)          \
     do                    \
@@ -63,27 +76,27 @@ int prepare(const TinySolver *s)
     const int nx = w->nx, nu = w->nu, N = w->N;
     if (!C.tb || C.nx != nx || C.nu != nu || C.N != N || C.device != g_device)
     {
-        if (C.tb) tiny_batch_destroy(C.tb);
+        if (C.tb) TB(destroy)(C.tb);
         C = Ctx();
-        TRYRC(tiny_batch_create(&C.tb, nx, nu, N, 1, g_device));
+        TRYRC(TB(create)(&C.tb, nx, nu, N, 1, g_device));
         C.nx = nx; C.nu = nu; C.N = N; C.device = g_device;
     }
     // problem class: one flat key {Kinf, Pinf, Quu_inv, AmBKt, Adyn, Bdyn, Q}
-    std::vector<float> key;
-    auto app = [&](const float *p, int n) { key.insert(key.end(), p, p + n); };
+    std::vector<real> key;
+    auto app = [&](const real *p, int n) { key.insert(key.end(), p, p + n); };
     app(c->Kinf, nu * nx); app(c->Pinf, nx * nx); app(c->Quu_inv, nu * nu); app(c->AmBKt, nx * nx);
     app(w->Adyn, nx * nx); app(w->Bdyn, nx * nu); app(w->Q, nx);
     if (key != C.gains || c->rho != C.rho)
     {
-        TRYRC(tiny_batch_set_cache(C.tb, c->rho, c->Kinf, c->Pinf, c->Quu_inv, c->AmBKt));
-        TRYRC(tiny_batch_set_dynamics(C.tb, w->Adyn, w->Bdyn, w->Q));
+        TRYRC(TB(set_cache)(C.tb, c->rho, c->Kinf, c->Pinf, c->Quu_inv, c->AmBKt));
+        TRYRC(TB(set_dynamics)(C.tb, w->Adyn, w->Bdyn, w->Q));
         C.gains.swap(key);
         C.rho = c->rho;
     }
-    TRYRC(tiny_batch_set_settings(C.tb, st->abs_pri_tol, st->abs_dua_tol, st->max_iter, st->check_termination,
+    TRYRC(TB(set_settings)(C.tb, st->abs_pri_tol, st->abs_dua_tol, st->max_iter, st->check_termination,
                                   st->en_state_bound, st->en_input_bound));
-    const float *bsrc[4] = {w->x_min, w->x_max, w->u_min, w->u_max};
-    int (*bset[4])(TinyBatch *, const float *, int) = {tiny_batch_set_xmin, tiny_batch_set_xmax, tiny_batch_set_umin, tiny_batch_set_umax};
+    const real *bsrc[4] = {w->x_min, w->x_max, w->u_min, w->u_max};
+    int (*bset[4])(Handle *, const real *, int) = {TB(set_xmin), TB(set_xmax), TB(set_umin), TB(set_umax)};
     for (int k = 0; k < 4; k++)
     {
         const size_t n = k < 2 ? (size_t)nx * N : (size_t)nu * (N - 1);
@@ -93,9 +106,10 @@ int prepare(const TinySolver *s)
     }
     if (!same(C.xref, w->Xref, (size_t)nx * N))
     {
-        TRYRC(tiny_batch_set_xref(C.tb, w->Xref, 1));
+        TRYRC(TB(set_xref)(C.tb, w->Xref, 1));
         C.xref.assign(w->Xref, w->Xref + (size_t)nx * N);
     }
+#ifndef TINYMPC_TINYTYPE_DOUBLE
     // the two terms the reference ships commented out (admm.cpp:20, :79): members read only when switched on
     if (g_en_uref) { NEED(w->R); NEED(w->Uref); }
     if (g_en_d2p) NEED(c->coeff_d2p);
@@ -113,31 +127,32 @@ int prepare(const TinySolver *s)
         C.opt.swap(opt);
     }
     TRYRC(tiny_batch_set_optional_terms(C.tb, g_en_uref, g_en_d2p));
+#endif
     return 0;
 }
 
-float *member(TinyWorkspace *w, int id)
+real *member(TinyWorkspace *w, int id)
 {
-    float *m[TINY_ARR_COUNT] = {w->x, w->u, w->q, w->r, w->p, w->d, w->v, w->vnew, w->z, w->znew, w->g, w->y};
+    real *m[TINY_ARR_COUNT] = {w->x, w->u, w->q, w->r, w->p, w->d, w->v, w->vnew, w->z, w->znew, w->g, w->y};
     return m[id];
 }
 
 int upload(TinySolver *s, std::initializer_list<int> ids)
 {
     TinyWorkspace *w = s->work;
-    for (int id : ids) TRYRC(tiny_batch_set_array(g_ctx.tb, id, member(w, id)));
-    const float res[4] = {w->primal_residual_state, w->primal_residual_input, w->dual_residual_state, w->dual_residual_input};
-    return tiny_batch_set_status(g_ctx.tb, &w->iter, &w->status, res);
+    for (int id : ids) TRYRC(TB(set_array)(g_ctx.tb, id, member(w, id)));
+    const real res[4] = {w->primal_residual_state, w->primal_residual_input, w->dual_residual_state, w->dual_residual_input};
+    return TB(set_status)(g_ctx.tb, &w->iter, &w->status, res);
 }
 
 int download(TinySolver *s, std::initializer_list<int> ids, bool scalars)
 {
     TinyWorkspace *w = s->work;
-    for (int id : ids) TRYRC(tiny_batch_get_array(g_ctx.tb, id, member(w, id)));
+    for (int id : ids) TRYRC(TB(get_array)(g_ctx.tb, id, member(w, id)));
     if (scalars)
     {
-        float res[4];
-        TRYRC(tiny_batch_get_status(g_ctx.tb, &w->iter, &w->status, res));
+        real res[4];
+        TRYRC(TB(get_status)(g_ctx.tb, &w->iter, &w->status, res));
         w->primal_residual_state = res[0]; w->primal_residual_input = res[1];
         w->dual_residual_state = res[2]; w->dual_residual_input = res[3];
     }
@@ -145,7 +160,7 @@ int download(TinySolver *s, std::initializer_list<int> ids, bool scalars)
 }
 
 // one step function: members read -> device, kernel, members written -> host
-int step(TinySolver *s, int (*fn)(TinyBatch *), std::initializer_list<int> in, std::initializer_list<int> out)
+int step(TinySolver *s, int (*fn)(Handle *), std::initializer_list<int> in, std::initializer_list<int> out)
 {
     TRYRC(prepare(s));
     TRYRC(upload(s, in));
@@ -166,6 +181,13 @@ int tiny_admm_set_device(int device)
 int tiny_admm_last_error_code(void) { return g_code; }
 int tiny_admm_set_optional_terms(int en_uref, int en_coeff_d2p)
 {
+#ifdef TINYMPC_TINYTYPE_DOUBLE
+    if (en_uref || en_coeff_d2p)
+    {
+        std::fprintf(stderr, "tinympc: the optional Uref / coeff_d2p terms are implemented by the float library only\n");
+        return g_code = TINY_BATCH_EUNSUPPORTED;
+    }
+#endif
     g_en_uref = en_uref != 0;
     g_en_d2p = en_coeff_d2p != 0;
     g_ctx.opt.clear();
@@ -178,44 +200,44 @@ int tiny_solve(TinySolver *s) // admm.cpp:111-152
     // live-in: x.col(0), d, y, g, v, z (+ p, which a solve that converges in its first iteration leaves as it was)
     if (rc >= 0) rc = upload(s, {TINY_ARR_X, TINY_ARR_P, TINY_ARR_D, TINY_ARR_V, TINY_ARR_Z, TINY_ARR_G, TINY_ARR_Y});
     int ret = 0;
-    if (rc >= 0) rc = ret = tiny_batch_solve(g_ctx.tb);
+    if (rc >= 0) rc = ret = TB(solve)(g_ctx.tb);
     if (rc >= 0 && s->settings->max_iter > 0) // max_iter <= 0 touches only status and iter (admm.cpp:114-117,151)
         rc = download(s, {TINY_ARR_X, TINY_ARR_U, TINY_ARR_Q, TINY_ARR_R, TINY_ARR_P, TINY_ARR_D, TINY_ARR_V, TINY_ARR_VNEW,
                           TINY_ARR_Z, TINY_ARR_ZNEW, TINY_ARR_G, TINY_ARR_Y}, true);
     else if (rc >= 0)
-        rc = tiny_batch_get_status(g_ctx.tb, &s->work->iter, &s->work->status, nullptr);
+        rc = TB(get_status)(g_ctx.tb, &s->work->iter, &s->work->status, nullptr);
     report("tiny_solve", rc);
     return rc < 0 ? rc : ret;
 }
 
 void forward_pass(TinySolver *s) // admm.cpp:27-37: reads x.col(0), d; writes u, x
 {
-    report("forward_pass", step(s, tiny_batch_forward_pass, {TINY_ARR_X, TINY_ARR_D}, {TINY_ARR_X, TINY_ARR_U}));
+    report("forward_pass", step(s, TB(forward_pass), {TINY_ARR_X, TINY_ARR_D}, {TINY_ARR_X, TINY_ARR_U}));
 }
 void update_slack(TinySolver *s) // admm.cpp:45-61: reads u, y, x, g, bounds; writes znew, vnew
 {
-    report("update_slack", step(s, tiny_batch_update_slack, {TINY_ARR_X, TINY_ARR_U, TINY_ARR_G, TINY_ARR_Y}, {TINY_ARR_VNEW, TINY_ARR_ZNEW}));
+    report("update_slack", step(s, TB(update_slack), {TINY_ARR_X, TINY_ARR_U, TINY_ARR_G, TINY_ARR_Y}, {TINY_ARR_VNEW, TINY_ARR_ZNEW}));
 }
 void update_dual(TinySolver *s) // admm.cpp:67-71: reads y, u, znew, g, x, vnew; writes y, g
 {
-    report("update_dual", step(s, tiny_batch_update_dual, {TINY_ARR_X, TINY_ARR_U, TINY_ARR_VNEW, TINY_ARR_ZNEW, TINY_ARR_G, TINY_ARR_Y},
+    report("update_dual", step(s, TB(update_dual), {TINY_ARR_X, TINY_ARR_U, TINY_ARR_VNEW, TINY_ARR_ZNEW, TINY_ARR_G, TINY_ARR_Y},
                                {TINY_ARR_G, TINY_ARR_Y}));
 }
 void update_linear_cost(TinySolver *s) // admm.cpp:77-85: reads znew, y, Xref, vnew, g; writes r, q, p.col(N-1)
 {
-    report("update_linear_cost", step(s, tiny_batch_update_linear_cost, {TINY_ARR_P, TINY_ARR_VNEW, TINY_ARR_ZNEW, TINY_ARR_G, TINY_ARR_Y},
+    report("update_linear_cost", step(s, TB(update_linear_cost), {TINY_ARR_P, TINY_ARR_VNEW, TINY_ARR_ZNEW, TINY_ARR_G, TINY_ARR_Y},
                                       {TINY_ARR_Q, TINY_ARR_R, TINY_ARR_P}));
 }
 void backward_pass_grad(TinySolver *s) // admm.cpp:15-22: reads p.col(N-1), q, r; writes d, p
 {
-    report("backward_pass_grad", step(s, tiny_batch_backward_pass_grad, {TINY_ARR_P, TINY_ARR_Q, TINY_ARR_R}, {TINY_ARR_P, TINY_ARR_D}));
+    report("backward_pass_grad", step(s, TB(backward_pass_grad), {TINY_ARR_P, TINY_ARR_Q, TINY_ARR_R}, {TINY_ARR_P, TINY_ARR_D}));
 }
 bool termination_condition(TinySolver *s) // admm.cpp:91-109: reads x, vnew, v, u, znew, z, iter; writes the residual fields
 {
     int conv = 0;
     int rc = prepare(s);
     if (rc >= 0) rc = upload(s, {TINY_ARR_X, TINY_ARR_U, TINY_ARR_V, TINY_ARR_VNEW, TINY_ARR_Z, TINY_ARR_ZNEW});
-    if (rc >= 0) rc = tiny_batch_termination_condition(g_ctx.tb, &conv);
+    if (rc >= 0) rc = TB(termination_condition)(g_ctx.tb, &conv);
     if (rc >= 0)
     {
         const int it = s->work->iter, stt = s->work->status; // not written by the reference function

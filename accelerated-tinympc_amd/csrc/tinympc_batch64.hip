@@ -573,6 +573,181 @@ __global__ __launch_bounds__(WAVE64, 1) void admm_f64_rows_kernel(const Params64
 #undef SN_SET
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The six functions tiny_solve() is made of (admm.hpp:12-18), one launch each, one thread per instance: each reads and writes
+// exactly the members the reference function does, in the same arithmetic as the fused kernels above.
+// ---------------------------------------------------------------------------------------------------------------------
+enum { F64_FORWARD_PASS = 0, F64_UPDATE_SLACK, F64_UPDATE_DUAL, F64_UPDATE_LINEAR_COST, F64_TERMINATION_CONDITION, F64_BACKWARD_PASS_GRAD };
+
+template <int NX, int NU, int FN>
+__global__ __launch_bounds__(WAVE64) void admm_f64_step_kernel(const Params64 P, int *__restrict__ conv_out)
+{
+    constexpr int NMAT = NU * NX + NX * NX + NU * NU + NX * NX + NX * NX + NX * NU + NX;
+    __shared__ double mats[NMAT];
+    for (int e = threadIdx.x; e < NMAT; e += WAVE64) mats[e] = P.mats[e];
+    __syncthreads();
+    const double *K = mats, *Pinf = K + NU * NX, *Quu = Pinf + NX * NX, *Am = Quu + NU * NU, *A = Am + NX * NX, *Bm = A + NX * NX,
+                 *Q = Bm + NX * NU;
+    const int b = blockIdx.x * WAVE64 + threadIdx.x;
+    if (b >= P.batch) return;
+    const int N = P.N;
+    const size_t bp = (size_t)P.bpad;
+    const double rho = P.rho;
+    auto at = [&](int id, int step, int row, int dim) -> double & { return P.arr[id][((size_t)step * dim + row) * bp + b]; };
+    auto in = [&](const double *base, int stride, int step, int row, int dim) {
+        return base[((size_t)step * dim + row) * (size_t)stride + (stride > 1 ? b : 0)];
+    };
+    if constexpr (FN == F64_FORWARD_PASS) // admm.cpp:27-37
+    {
+        double x[NX];
+#pragma unroll
+        for (int j = 0; j < NX; j++) x[j] = at(TINY_ARR_X, 0, j, NX);
+        for (int i = 0; i < N - 1; i++)
+        {
+            double u[NU], xn[NX];
+#pragma unroll
+            for (int j = 0; j < NU; j++) u[j] = -row_dot<NU, NX>(K, j, x) - at(TINY_ARR_D, i, j, NU);
+#pragma unroll
+            for (int j = 0; j < NX; j++) xn[j] = row_dot<NX, NX>(A, j, x) + row_dot<NX, NU>(Bm, j, u);
+#pragma unroll
+            for (int j = 0; j < NU; j++) at(TINY_ARR_U, i, j, NU) = u[j];
+#pragma unroll
+            for (int j = 0; j < NX; j++) { at(TINY_ARR_X, i + 1, j, NX) = xn[j]; x[j] = xn[j]; }
+        }
+    }
+    else if constexpr (FN == F64_UPDATE_SLACK) // admm.cpp:45-61
+    {
+        for (int i = 0; i < N - 1; i++)
+#pragma unroll
+            for (int j = 0; j < NU; j++)
+            {
+                double zn = at(TINY_ARR_U, i, j, NU) + at(TINY_ARR_Y, i, j, NU);
+                if (P.en_input_bound)
+                {
+                    const double lo = in(P.umin, P.ub_stride, i, j, NU), hi = in(P.umax, P.ub_stride, i, j, NU);
+                    zn = (lo < zn) ? zn : lo;
+                    zn = (zn < hi) ? zn : hi;
+                }
+                at(TINY_ARR_ZNEW, i, j, NU) = zn;
+            }
+        for (int i = 0; i < N; i++)
+#pragma unroll
+            for (int j = 0; j < NX; j++)
+            {
+                double vn = at(TINY_ARR_X, i, j, NX) + at(TINY_ARR_G, i, j, NX);
+                if (P.en_state_bound)
+                {
+                    const double lo = in(P.xmin, P.xb_stride, i, j, NX), hi = in(P.xmax, P.xb_stride, i, j, NX);
+                    vn = (lo < vn) ? vn : lo;
+                    vn = (vn < hi) ? vn : hi;
+                }
+                at(TINY_ARR_VNEW, i, j, NX) = vn;
+            }
+    }
+    else if constexpr (FN == F64_UPDATE_DUAL) // admm.cpp:67-71
+    {
+        for (int i = 0; i < N - 1; i++)
+#pragma unroll
+            for (int j = 0; j < NU; j++) at(TINY_ARR_Y, i, j, NU) = at(TINY_ARR_Y, i, j, NU) + at(TINY_ARR_U, i, j, NU) - at(TINY_ARR_ZNEW, i, j, NU);
+        for (int i = 0; i < N; i++)
+#pragma unroll
+            for (int j = 0; j < NX; j++) at(TINY_ARR_G, i, j, NX) = at(TINY_ARR_G, i, j, NX) + at(TINY_ARR_X, i, j, NX) - at(TINY_ARR_VNEW, i, j, NX);
+    }
+    else if constexpr (FN == F64_UPDATE_LINEAR_COST) // admm.cpp:77-85
+    {
+        for (int i = 0; i < N - 1; i++)
+#pragma unroll
+            for (int j = 0; j < NU; j++) at(TINY_ARR_R, i, j, NU) = -rho * (at(TINY_ARR_ZNEW, i, j, NU) - at(TINY_ARR_Y, i, j, NU));
+        for (int i = 0; i < N; i++)
+#pragma unroll
+            for (int j = 0; j < NX; j++)
+            {
+                double q = -(in(P.xref, P.xref_stride, i, j, NX) * Q[j]);
+                q = q - rho * (at(TINY_ARR_VNEW, i, j, NX) - at(TINY_ARR_G, i, j, NX));
+                at(TINY_ARR_Q, i, j, NX) = q;
+            }
+        double xr[NX];
+#pragma unroll
+        for (int k = 0; k < NX; k++) xr[k] = in(P.xref, P.xref_stride, N - 1, k, NX);
+#pragma unroll
+        for (int j = 0; j < NX; j++)
+        {
+            double t[NX];
+#pragma unroll
+            for (int k = 0; k < NX; k++) t[k] = xr[k] * Pinf[j * NX + k];
+            const double pt = -vec_sum(t);
+            at(TINY_ARR_P, N - 1, j, NX) = pt - rho * (at(TINY_ARR_VNEW, N - 1, j, NX) - at(TINY_ARR_G, N - 1, j, NX));
+        }
+    }
+    else if constexpr (FN == F64_TERMINATION_CONDITION) // admm.cpp:91-109
+    {
+        bool conv = false;
+        if (P.iter[b] % P.check_termination == 0)
+        {
+            double pri_x = 0, dua_x = 0, pri_u = 0, dua_u = 0;
+            for (int i = 0; i < N; i++)
+#pragma unroll
+                for (int j = 0; j < NX; j++)
+                {
+                    const double vn = at(TINY_ARR_VNEW, i, j, NX);
+                    const double px = fabs(at(TINY_ARR_X, i, j, NX) - vn), dx = fabs(at(TINY_ARR_V, i, j, NX) - vn);
+                    pri_x = (i == 0 && j == 0) ? px : (px > pri_x ? px : pri_x);
+                    dua_x = (i == 0 && j == 0) ? dx : (dx > dua_x ? dx : dua_x);
+                }
+            for (int i = 0; i < N - 1; i++)
+#pragma unroll
+                for (int j = 0; j < NU; j++)
+                {
+                    const double zn = at(TINY_ARR_ZNEW, i, j, NU);
+                    const double pu = fabs(at(TINY_ARR_U, i, j, NU) - zn), du = fabs(at(TINY_ARR_Z, i, j, NU) - zn);
+                    pri_u = (i == 0 && j == 0) ? pu : (pu > pri_u ? pu : pri_u);
+                    dua_u = (i == 0 && j == 0) ? du : (du > dua_u ? du : dua_u);
+                }
+            const double r_ps = pri_x, r_ds = dua_x * rho, r_pi = pri_u, r_di = dua_u * rho;
+            P.res[0 * bp + b] = r_ps; P.res[1 * bp + b] = r_pi; P.res[2 * bp + b] = r_ds; P.res[3 * bp + b] = r_di;
+            conv = (r_ps < P.abs_pri_tol) && (r_pi < P.abs_pri_tol) && (r_ds < P.abs_dua_tol) && (r_di < P.abs_dua_tol);
+        }
+        conv_out[b] = conv ? 1 : 0;
+    }
+    else // F64_BACKWARD_PASS_GRAD, admm.cpp:15-22
+    {
+        double pn[NX];
+#pragma unroll
+        for (int j = 0; j < NX; j++) pn[j] = at(TINY_ARR_P, N - 1, j, NX);
+        for (int i = N - 2; i >= 0; i--)
+        {
+            double r[NU], tmp[NU], dn[NU], pi[NX];
+#pragma unroll
+            for (int j = 0; j < NU; j++) r[j] = at(TINY_ARR_R, i, j, NU);
+#pragma unroll
+            for (int j = 0; j < NU; j++)
+            {
+                double t[NX];
+#pragma unroll
+                for (int k = 0; k < NX; k++) t[k] = Bm[j * NX + k] * pn[k];
+                tmp[j] = vec_sum(t) + r[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NU; j++) dn[j] = row_dot<NU, NU>(Quu, j, tmp);
+#pragma unroll
+            for (int j = 0; j < NX; j++)
+            {
+                double t[NX], tk[NU];
+#pragma unroll
+                for (int k = 0; k < NX; k++) t[k] = Am[k * NX + j] * pn[k];
+                const double a = (NU == 1 && NX % PS == 0) ? seq_sum(t) : novec_sum(t);
+#pragma unroll
+                for (int m = 0; m < NU; m++) tk[m] = K[j * NU + m] * r[m];
+                pi[j] = at(TINY_ARR_Q, i, j, NX) + a - vec_sum(tk);
+            }
+#pragma unroll
+            for (int j = 0; j < NU; j++) at(TINY_ARR_D, i, j, NU) = dn[j];
+#pragma unroll
+            for (int j = 0; j < NX; j++) { at(TINY_ARR_P, i, j, NX) = pi[j]; pn[j] = pi[j]; }
+        }
+    }
+}
+
 // host layout [cnt][steps][dim] (cnt = 1: shared, stored once with stride 1)  <->  device [steps][dim][stride]
 __global__ void pack64_kernel(const double *__restrict__ src, double *__restrict__ dst, int nb, int steps, int dim, int stride, int step0, int nsteps)
 {
@@ -748,6 +923,49 @@ int set_input(TinyBatch64 *tb, int which, const double *src, int shared)
     tb->in_set[which] = true;
     return 0;
 }
+int prepare64(TinyBatch64 *tb, Params64 &P)
+{
+    if (!tb->have_cache || !tb->have_dyn || !tb->have_settings)
+        return fail64(TINY_BATCH_ENOTREADY, "set_cache, set_dynamics and set_settings must be called first");
+    if (tb->in_stride[1] != tb->in_stride[2] || tb->in_stride[3] != tb->in_stride[4])
+        return fail64(TINY_BATCH_EINVAL, "min and max bounds must both be shared or both be per-instance");
+    HIP64(hipSetDevice(tb->device));
+    if (tb->mats_dirty)
+    {
+        HIP64(hipMemcpy(tb->mats, tb->hm.data(), tb->hm.size() * sizeof(double), hipMemcpyHostToDevice));
+        const std::vector<double> g = pack_row_gains(tb);
+        if (!tb->row_gains) HIP64(hipMalloc((void **)&tb->row_gains, g.size() * sizeof(double)));
+        HIP64(hipMemcpy(tb->row_gains, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
+        tb->mats_dirty = false;
+    }
+    P.nx = tb->nx; P.nu = tb->nu; P.N = tb->N; P.batch = tb->batch; P.bpad = tb->bpad;
+    P.rho = tb->rho; P.abs_pri_tol = tb->abs_pri_tol; P.abs_dua_tol = tb->abs_dua_tol;
+    P.max_iter = tb->max_iter; P.check_termination = tb->check_termination;
+    P.en_state_bound = tb->en_state_bound; P.en_input_bound = tb->en_input_bound;
+    for (int id = 0; id < TINY_ARR_COUNT; id++) P.arr[id] = tb->arr[id];
+    P.xref = tb->in[0]; P.xmin = tb->in[1]; P.xmax = tb->in[2]; P.umin = tb->in[3]; P.umax = tb->in[4];
+    P.xref_stride = tb->in_stride[0]; P.xb_stride = tb->in_stride[1]; P.ub_stride = tb->in_stride[3];
+    P.mats = tb->mats; P.res = tb->res; P.status = tb->status; P.iter = tb->iter; P.n_unsolved = tb->n_unsolved;
+    return 0;
+}
+
+// one of the six step functions over the whole batch
+template <int FN>
+int run_step64(TinyBatch64 *tb, int *conv_dev)
+{
+    CHECK64(tb, "NULL handle");
+    Params64 P;
+    int rc = prepare64(tb, P);
+    if (rc < 0) return rc;
+    const int nblocks = tb->bpad / WAVE64;
+    if (tb->nx == 12 && tb->nu == 4) hipLaunchKernelGGL((admm_f64_step_kernel<12, 4, FN>), dim3(nblocks), dim3(WAVE64), 0, 0, P, conv_dev);
+    else if (tb->nx == 4 && tb->nu == 1) hipLaunchKernelGGL((admm_f64_step_kernel<4, 1, FN>), dim3(nblocks), dim3(WAVE64), 0, 0, P, conv_dev);
+    else hipLaunchKernelGGL((admm_f64_step_kernel<8, 4, FN>), dim3(nblocks), dim3(WAVE64), 0, 0, P, conv_dev);
+    HIP64(hipGetLastError());
+    HIP64(hipDeviceSynchronize());
+    return 0;
+}
+
 } // namespace
 
 extern "C"
@@ -865,34 +1083,35 @@ int tiny_batch64_reset_dual_variables(TinyBatch64 *tb)
     return 0;
 }
 
+int tiny_batch64_forward_pass(TinyBatch64 *tb) { return run_step64<F64_FORWARD_PASS>(tb, nullptr); }
+int tiny_batch64_update_slack(TinyBatch64 *tb) { return run_step64<F64_UPDATE_SLACK>(tb, nullptr); }
+int tiny_batch64_update_dual(TinyBatch64 *tb) { return run_step64<F64_UPDATE_DUAL>(tb, nullptr); }
+int tiny_batch64_update_linear_cost(TinyBatch64 *tb) { return run_step64<F64_UPDATE_LINEAR_COST>(tb, nullptr); }
+int tiny_batch64_backward_pass_grad(TinyBatch64 *tb) { return run_step64<F64_BACKWARD_PASS_GRAD>(tb, nullptr); }
+int tiny_batch64_termination_condition(TinyBatch64 *tb, int *converged)
+{
+    CHECK64(tb && converged, "NULL argument");
+    HIP64(hipSetDevice(tb->device));
+    int *dev = nullptr;
+    HIP64(hipMalloc((void **)&dev, (size_t)tb->bpad * sizeof(int)));
+    int rc = run_step64<F64_TERMINATION_CONDITION>(tb, dev);
+    if (rc >= 0 && hipMemcpy(converged, dev, (size_t)tb->batch * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail64(TINY_BATCH_EHIP, "copying the termination flags back failed");
+    (void)hipFree(dev);
+    return rc;
+}
+
 int tiny_batch64_solve(TinyBatch64 *tb)
 {
     CHECK64(tb, "NULL handle");
-    if (!tb->have_cache || !tb->have_dyn || !tb->have_settings)
-        return fail64(TINY_BATCH_ENOTREADY, "tiny_batch64_solve: set_cache, set_dynamics and set_settings must be called first");
-    if (tb->in_stride[1] != tb->in_stride[2] || tb->in_stride[3] != tb->in_stride[4])
-        return fail64(TINY_BATCH_EINVAL, "min and max bounds must both be shared or both be per-instance");
-    HIP64(hipSetDevice(tb->device));
-    if (tb->mats_dirty)
+    Params64 P;
     {
-        HIP64(hipMemcpy(tb->mats, tb->hm.data(), tb->hm.size() * sizeof(double), hipMemcpyHostToDevice));
-        const std::vector<double> g = pack_row_gains(tb);
-        if (!tb->row_gains) HIP64(hipMalloc((void **)&tb->row_gains, g.size() * sizeof(double)));
-        HIP64(hipMemcpy(tb->row_gains, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
-        tb->mats_dirty = false;
+        const int rc = prepare64(tb, P);
+        if (rc < 0) return rc;
     }
     const bool rows = tb->kernel_choice == 2 || (tb->kernel_choice == 0 && rows_supported(tb->nx, tb->nu, tb->N));
     if (rows && !rows_supported(tb->nx, tb->nu, tb->N))
         return fail64(TINY_BATCH_EUNSUPPORTED, "the sixteen-lane fp64 kernel has no instantiation for nx=%d nu=%d N=%d", tb->nx, tb->nu, tb->N);
-    Params64 P;
-    P.nx = tb->nx; P.nu = tb->nu; P.N = tb->N; P.batch = tb->batch; P.bpad = tb->bpad;
-    P.rho = tb->rho; P.abs_pri_tol = tb->abs_pri_tol; P.abs_dua_tol = tb->abs_dua_tol;
-    P.max_iter = tb->max_iter; P.check_termination = tb->check_termination;
-    P.en_state_bound = tb->en_state_bound; P.en_input_bound = tb->en_input_bound;
-    for (int id = 0; id < TINY_ARR_COUNT; id++) P.arr[id] = tb->arr[id];
-    P.xref = tb->in[0]; P.xmin = tb->in[1]; P.xmax = tb->in[2]; P.umin = tb->in[3]; P.umax = tb->in[4];
-    P.xref_stride = tb->in_stride[0]; P.xb_stride = tb->in_stride[1]; P.ub_stride = tb->in_stride[3];
-    P.mats = tb->mats; P.res = tb->res; P.status = tb->status; P.iter = tb->iter; P.n_unsolved = tb->n_unsolved;
     HIP64(hipMemset(tb->n_unsolved, 0, sizeof(int)));
     const int nblocks = tb->bpad / WAVE64;
     if (rows)

@@ -95,6 +95,8 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch64_set_array": [P, C.c_int, D], "tiny_batch64_get_array": [P, C.c_int, D],
         "tiny_batch64_get_status": [P, I, I, D], "tiny_batch64_set_status": [P, I, I, D],
         "tiny_batch64_select_kernel": [P, C.c_int], "tiny_batch64_mpc_step": [P], "tiny_batch64_get_first_columns": [P, D, D],
+        "tiny_batch64_forward_pass": [P], "tiny_batch64_update_slack": [P], "tiny_batch64_update_dual": [P],
+        "tiny_batch64_update_linear_cost": [P], "tiny_batch64_backward_pass_grad": [P], "tiny_batch64_termination_condition": [P, I],
     }
     for name, args in sig64.items():
         fn = getattr(lib, name)
@@ -466,6 +468,18 @@ class TinyBatchSolver64:
         self._check(self.lib.tiny_batch64_select_kernel(self._h, which))
 
     def kernel_name(self) -> str: return self.lib.tiny_batch64_kernel_name(self._h).decode()
+
+    # -- the six step functions of admm.hpp:12-18 ----------------------------------------------------
+    def forward_pass(self): self._check(self.lib.tiny_batch64_forward_pass(self._h))
+    def update_slack(self): self._check(self.lib.tiny_batch64_update_slack(self._h))
+    def update_dual(self): self._check(self.lib.tiny_batch64_update_dual(self._h))
+    def update_linear_cost(self): self._check(self.lib.tiny_batch64_update_linear_cost(self._h))
+    def backward_pass_grad(self): self._check(self.lib.tiny_batch64_backward_pass_grad(self._h))
+
+    def termination_condition(self):
+        conv = np.zeros(self.B, np.int32)
+        self._check(self.lib.tiny_batch64_termination_condition(self._h, conv.ctypes.data_as(C.POINTER(C.c_int))))
+        return conv.astype(bool)
 
     def mpc_step(self) -> int:
         """y = g = 0, tiny_solve, x.col(0) <- Adyn x.col(0) + Bdyn u.col(0) (quadrotor_hovering.cpp:95-111), on the device."""

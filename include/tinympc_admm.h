@@ -25,7 +25,15 @@ extern "C"
 {
 #endif
 
-    typedef float tinytype; /* codegen.cpp:152: generated code is always float */
+    /* codegen.cpp:152: generated code is always float — the default here, served by libtinympc_wrapper.so.  Define
+     * TINYMPC_TINYTYPE_DOUBLE before including this header for the reference as it is checked in (glob_opts.hpp:3:
+     * typedef double tinytype) and link libtinympc_wrapper64.so instead: same names, same structs with double members,
+     * results bitwise equal to the reference's fp64 build (classes (12,4), (4,1), (8,4); the optional terms are float only). */
+#ifdef TINYMPC_TINYTYPE_DOUBLE
+    typedef double tinytype;
+#else
+    typedef float tinytype;
+#endif
 
     /* types.hpp:26-34.  Matrices column-major: Kinf nu x nx, Pinf nx x nx, Quu_inv nu x nu, AmBKt nx x nx.
      * coeff_d2p (nx x nu) is not read by the solver (admm.cpp:20 has the term commented out) and may be NULL, unless

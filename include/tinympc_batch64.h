@@ -54,6 +54,17 @@ extern "C"
     /* tiny_solve() for every instance (admm.cpp:111-152): 0 = all converged, 1 = some hit max_iter, < 0 = error */
     int tiny_batch64_solve(TinyBatch64 *tb);
 
+    /* The six functions tiny_solve() is made of (admm.hpp:12-18, admm.cpp:15-109), each over the whole batch: one launch that reads
+     * and writes the members the reference function does.  termination_condition evaluates `work->iter % check_termination`
+     * with the iter field of the workspace (set_status), writes the four residual fields when that holds and returns the
+     * function's bool per instance in converged[batch]. */
+    int tiny_batch64_forward_pass(TinyBatch64 *tb);
+    int tiny_batch64_update_slack(TinyBatch64 *tb);
+    int tiny_batch64_update_dual(TinyBatch64 *tb);
+    int tiny_batch64_update_linear_cost(TinyBatch64 *tb);
+    int tiny_batch64_backward_pass_grad(TinyBatch64 *tb);
+    int tiny_batch64_termination_condition(TinyBatch64 *tb, int *converged);
+
     /* One step of the examples' closed loop (quadrotor_hovering.cpp:95-111) on the device: y = g = 0, tiny_solve, then the plant
      * update x.col(0) <- Adyn * x.col(0) + Bdyn * u.col(0) in the order Eigen evaluates that expression (bitwise equal to
      * the compiled example).  Returns what tiny_batch64_solve returns.  tiny_batch64_get_first_columns reads x.col(0) (after the

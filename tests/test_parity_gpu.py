@@ -1947,6 +1947,94 @@ def test_fp64_as_shipped_hovering_loop_and_golden_vectors(tinympc, oracle_mod, k
     sol.close()
 
 
+@pytest.mark.parametrize("case", ["quad10", "cartpole", "r8_4"])
+def test_fp64_step_functions_batched_and_native(tinympc, oracle_mod, case):
+    """The six step functions in double: over a batch (tiny_batch64_forward_pass ...) and under the reference's own names over a
+    caller-owned TinySolver with double members (libtinympc_wrapper64.so: the reference as checked in).  Each call leaves the
+    workspace exactly as the fp64 oracle's restatement of the same reference function; tiny_solve from a random warm state too."""
+    from accelerated_tinympc_amd import native
+    O, pr = oracle_mod, tinympc.problems
+    prob = {"quad10": lambda: pr.quadrotor(20, 10), "cartpole": lambda: pr.cartpole(10, riccati=O.riccati),
+            "r8_4": lambda: pr.random_system(8, 4, 9, seed=804, riccati=O.riccati)}[case]()
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    B = 70
+    rng = np.random.default_rng(21)
+    bnds = tuple(np.asarray(a, np.float64) * s for a, s in zip(pr.bounds_arrays(prob, np.float64), (0.2, 0.2, 1.0, 1.0)))
+    settings = dict(O.DEFAULT_SETTINGS, check_termination=2, abs_pri_tol=0.5, abs_dua_tol=5.0)
+    st = O.new_state(B, nx, nu, N, np.float64)
+    for k in STATE_ORDER:
+        st[k][:] = rng.standard_normal(st[k].shape) * 0.3
+    st["iter"][:] = 4; st["status"][:] = 11
+    st["iter"][::3] = 5   # odd: termination_condition must skip these (iter % check_termination != 0)
+    st["residuals"][:] = rng.uniform(0, 1, size=(B, 4))
+    xref = rng.standard_normal((B, N, nx)) * 0.3
+    orc = O.Oracle(prob, np.float64, settings)
+    sol = tinympc.TinyBatchSolver64(prob, B, settings=settings)
+    sol.set_bounds(*bnds); sol.set_xref(xref)
+    ns = native.NativeSolver(prob, settings, dtype=np.float64)
+    for k, arr in zip(("x_min", "x_max", "u_min", "u_max"), bnds):
+        ns.a[k][:] = arr
+    ns.a["Xref"][:] = xref[0]
+
+    def load_native(state):
+        for k in STATE_ORDER:
+            ns.a[k][:] = state[k][0]
+        w = ns.work
+        (w.primal_residual_state, w.primal_residual_input, w.dual_residual_state, w.dual_residual_input) = map(float, state["residuals"][0])
+        w.iter, w.status = int(state["iter"][0]), int(state["status"][0])
+
+    for fn in O.Oracle.STEP_FUNCTIONS:
+        sol.set_state(st); load_native(st)
+        ref_rv = orc.step(fn, st, *bnds, xref)
+        rv = getattr(sol, fn)()
+        rvn = ns.call(fn)
+        got = sol.get_state()
+        if fn == "termination_condition":
+            assert np.array_equal(rv, ref_rv) and bool(rvn) == bool(ref_rv[0])
+        for k in STATE_ORDER + ("residuals",):
+            assert np.array_equal(got[k], st[k]) and np.array_equal(np.signbit(got[k]), np.signbit(st[k])), f"batched {fn}: {k}"
+        for k in STATE_ORDER:
+            assert np.array_equal(ns.a[k], st[k][0]), f"native {fn}: {k}"
+        assert np.array_equal(ns.residuals, st["residuals"][0]) and ns.work.iter == st["iter"][0] and ns.work.status == st["status"][0], fn
+    for max_iter in (3, 200):
+        settings2 = dict(settings, max_iter=max_iter, check_termination=1, abs_pri_tol=1e-3, abs_dua_tol=1e-3)
+        ns.settings.max_iter, ns.settings.check_termination = max_iter, 1
+        ns.settings.abs_pri_tol = ns.settings.abs_dua_tol = 1e-3
+        st2 = O.copy_state(st)
+        load_native(st2)
+        O.Oracle(prob, np.float64, settings2).solve(st2, *bnds, xref)
+        rc = ns.tiny_solve()
+        assert rc == (1 if st2["status"][0] == 11 else 0)
+        for k in STATE_ORDER:
+            assert np.array_equal(ns.a[k], st2[k][0]), f"native tiny_solve max_iter={max_iter}: {k}"
+        assert ns.work.iter == st2["iter"][0] and ns.work.status == st2["status"][0]
+    sol.close()
+
+
+def test_fp64_native_names_as_shipped_hovering_loop(tinympc, oracle_mod):
+    """examples/quadrotor_hovering.cpp exactly as the reference is checked in — typedef double tinytype, N = 10 — written against
+    include/tinympc_admm.h with TINYMPC_TINYTYPE_DOUBLE: TinySolver{settings, cache, work} with double members, tiny_solve(&solver)
+    in the loop of :90-114.  Iteration counts and controls of all 70 steps equal the compiled example's (1 269 iterations)."""
+    from accelerated_tinympc_amd import native
+    O = oracle_mod
+    meta, prob, solves, z = load_fixture("quad_hover_f64_N10")
+    ns = native.NativeSolver(prob, solves[0]["settings"], dtype=np.float64)
+    for k, arr in zip(("x_min", "x_max", "u_min", "u_max"), bounds_of(prob, np.float64)):
+        ns.a[k][:] = arr
+    ns.a["Xref"][:] = solves[0]["xref"]
+    orc = O.Oracle(prob, np.float64)
+    x0 = solves[0]["pre"]["x"][0, 0].copy()
+    iters, u0s = [], []
+    for k in range(70):
+        ns.a["x"][0] = x0
+        ns.a["y"][:] = 0; ns.a["g"][:] = 0
+        ns.tiny_solve()
+        iters.append(ns.work.iter); u0s.append(ns.a["u"][0].copy())
+        x0 = orc.plant_step(x0[None], ns.a["u"][0][None])[0]
+    assert np.array_equal(np.array(iters), z["trace_iter"]) and np.array_equal(np.array(u0s), z["trace_u0"][:, :] if z["trace_u0"].ndim == 2 else z["trace_u0"])
+    assert sum(iters) == 1269
+
+
 @pytest.mark.parametrize("nx,nu,N", [(4, 1, 10), (8, 4, 9), (12, 4, 30)])
 def test_fp64_device_closed_loop_vs_oracle(tinympc, oracle_mod, nx, nu, N):
     """tiny_batch64_mpc_step over a batch: 12 closed-loop steps equal the oracle's solve + its plant step (pinned against the
