@@ -349,7 +349,7 @@ __device__ __forceinline__ double lazy_sum(const double (&t)[CNT])
 constexpr int F64_AHEAD = 4; // bounds are fetched this many steps ahead of their use
 
 template <int NX, int NU, int N>
-__global__ __launch_bounds__(WAVE64, 1) void admm_f64_rows_kernel(const Params64 P, const double *__restrict__ gains)
+__global__ __launch_bounds__(WAVE64, (N <= 12 ? 2 : 1)) void admm_f64_rows_kernel(const Params64 P, const double *__restrict__ gains)
 {
     static_assert(NX + NU <= 16 && !(NX >= 8 && NU >= 8), "16-lane mapping; both dims >= 8 would take Eigen's GEMV kernel");
     const int lane = threadIdx.x, r16 = lane & 15;
