@@ -980,12 +980,20 @@ int set_bound(TinyBatch *tb, const float *src, int shared, int which)
     return store_input(tb, tb->in_bnd[which], src, shared != 0, xf ? tb->N : tb->N - 1, xf ? tb->nx : tb->nu);
 }
 
-bool stream_dims_supported(int nxc, int nuc)
+// The MFMA streaming kernel is instantiated per (chunks of 4 state rows, chunks of 4 input rows).  A class without its own
+// instantiation runs on the smallest one that contains it: the extra chunks are rows that do not exist (zero gains, zero
+// state, no bounds — exactly like the unused rows of a partly filled chunk), so any nx <= 64, nu <= 32 is served.
+bool stream_dims_supported(int nxc, int nuc, int *pxc, int *puc)
 {
-#define TINY_CHECK_DIMS(NXC, NUC) \
-    if (nxc == NXC && nuc == NUC) return true;
+    int best = 1 << 30;
+    bool found = false;
+#define TINY_CHECK_DIMS(NXC, NUC)                                        \
+    if (nxc <= NXC && nuc <= NUC && (NXC + NUC) * 64 + NXC < best)       \
+    {                                                                    \
+        best = (NXC + NUC) * 64 + NXC; *pxc = NXC; *puc = NUC; found = true; \
+    }
     TINY_FOR_EACH_DIMS(TINY_CHECK_DIMS)
-    return false;
+    return found;
 }
 
 } // namespace
@@ -1001,14 +1009,15 @@ int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int dev
     *out = nullptr;
     if (nx < 1 || nu < 1 || N < 2 || batch < 1)
         return fail(TINY_BATCH_EINVAL, "tiny_batch_create: need nx>=1, nu>=1, N>=2, batch>=1 (got %d,%d,%d,%d)", nx, nu, N, batch);
-    const int nxc = (nx + 3) / 4, nuc = (nu + 3) / 4;
+    int nxc = (nx + 3) / 4, nuc = (nu + 3) / 4;
     // the rowlane kernel addresses its arrays with 32-bit element offsets
-    const bool tile_ok = stream_dims_supported(nxc, nuc),
+    const bool tile_ok = stream_dims_supported(nxc, nuc, &nxc, &nuc),
                row_ok = rowlane_supported(nx, nu, N) && ((long long)(batch + 3) * N * 16 < (1ll << 30));
     const bool wave_ok = !rowdims_supported(nx, nu) && wavedims_supported(nx, nu) && ((long long)(batch + 3) * N * 64 < (1ll << 30));
     if (!tile_ok && !row_ok && !rowdims_supported(nx, nu) && !wave_ok)
         return fail(TINY_BATCH_EUNSUPPORTED,
-                    "no kernel instantiation for nx=%d nu=%d N=%d; add it to TINY_FOR_EACH_DIMS / TINY_FOR_EACH_ROWLANE", nx, nu, N);
+                    "no kernel for nx=%d nu=%d N=%d: exact arithmetic needs a compiled class (TINY_FOR_EACH_ROWDIMS / _WAVEDIMS), fma arithmetic nx <= 64 and nu <= 32",
+                    nx, nu, N);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(TINY_BATCH_EINVAL, "device %d out of range (have %d)", device, ndev);

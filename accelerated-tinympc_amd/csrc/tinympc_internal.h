@@ -26,7 +26,7 @@ constexpr int TINY_STATUS_SOLVED_ = 1;    // work->status, admm.cpp:136
 constexpr int TINY_STATUS_UNSOLVED_ = 11; // admm.cpp:114
 
 // (NXC, NUC) pairs with compiled kernels: quadrotor (12,4), cartpole (4,1), random (32,16), test dims (8,3)
-#define TINY_FOR_EACH_DIMS(X) X(3, 1) X(1, 1) X(8, 4) X(2, 1)
+#define TINY_FOR_EACH_DIMS(X) X(3, 1) X(1, 1) X(8, 4) X(2, 1) X(16, 8)
 
 template <int NXC_, int NUC_>
 struct Dims

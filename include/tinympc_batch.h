@@ -61,7 +61,11 @@ extern "C"
     /* Allocates the device-resident workspaces of `batch` instances on HIP device `device`, all
      * zero (the state the reference examples start from, quadrotor_hovering.cpp:49-71).
      * Replaces: the caller-owned TinyCache/TinyWorkspace/TinySettings/TinySolver globals
-     * (types.hpp:26-107, quadrotor_hovering.cpp:25-28). */
+     * (types.hpp:26-107, quadrotor_hovering.cpp:25-28).
+     * Dimensions (glob_opts.hpp:5-7 fixes them at compile time; here they are arguments): any nx <= 64, nu <= 32, N >= 2.
+     * Classes with a compiled exact kernel — (nx, nu) = (12,4), (4,1), (8,3), (8,4), (12,2), (4,2), (4,4), (32,16), (16,8),
+     * (16,4) — compute bitwise what the reference computes; any other class runs in fma arithmetic on the MFMA streaming
+     * kernel (tiny_batch_kernel_name reports "stream<...>").  Beyond those limits: TINY_BATCH_EUNSUPPORTED. */
     int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int device);
     void tiny_batch_destroy(TinyBatch *tb);
     /* Launch on this hipStream_t (passed as void*; NULL = the null stream).  Default: NULL. */

@@ -403,8 +403,8 @@ def test_errors_are_reported_not_swallowed(tinympc):
     pr = tinympc.problems
     prob = pr.quadrotor(20, 30)
     with pytest.raises(tinympc.TinyBatchError):
-        tinympc.TinyBatchSolver(dict(prob, nx=20, Kinf=np.zeros((4, 20)), Pinf=np.zeros((20, 20)), AmBKt=np.zeros((20, 20)),
-                                     Adyn=np.zeros((20, 20)), Bdyn=np.zeros((20, 4)), Q=np.zeros(20)), 4)  # no (5,1) kernel
+        tinympc.TinyBatchSolver(dict(prob, nx=72, Kinf=np.zeros((4, 72)), Pinf=np.zeros((72, 72)), AmBKt=np.zeros((72, 72)),
+                                     Adyn=np.zeros((72, 72)), Bdyn=np.zeros((72, 4)), Q=np.zeros(72)), 4)  # nx > 64: no kernel
     sol = tinympc.TinyBatchSolver(prob, 4)
     with pytest.raises(tinympc.TinyBatchError):
         sol.set_xref_window(np.zeros((20, 12), np.float32), np.zeros(4, np.int32))  # table shorter than N
@@ -1072,6 +1072,44 @@ def test_wave_kernel_fma_arithmetic(tinympc, oracle_mod, dims):
             compare_states(sol.get_state(), st, prob, f"waveres fast {dims} {extra} k={k}", ref64=ref64, fixed=fixed)
             sol.set_state(st)
         sol.close()
+
+
+@pytest.mark.parametrize("dims", [(20, 8, 12), (6, 2, 9), (30, 10, 7), (5, 5, 8), (3, 2, 6), (10, 3, 11), (40, 12, 6), (64, 32, 4), (33, 17, 5)])
+def test_classes_without_an_instantiation_run_on_the_padded_mfma_kernel(tinympc, oracle_mod, dims):
+    """The reference takes any NSTATES / NINPUTS / NHORIZON (glob_opts.hpp:5-7).  A class with no compiled exact kernel is
+    served, in fma arithmetic, by the smallest MFMA streaming instantiation that contains it (any nx <= 64, nu <= 32, any N):
+    fixed-iteration results agree with the CPU restatement of the reference (plain sequential sums for these dimensions,
+    whose order the reference leaves to Eigen's alignment logic) to fp32 rounding, early exit converges the same instances."""
+    O, pr = oracle_mod, tinympc.problems
+    nx, nu, N = dims
+    prob = pr.random_system(nx, nu, N, seed=nx * 31 + nu)
+    B = 53
+    rng = np.random.default_rng(N)
+    x0 = rng.uniform(-0.5, 0.5, size=(B, nx)).astype(np.float32)
+    xref = (rng.standard_normal((B, N, nx)) * 0.1).astype(np.float32)
+    bnds = pr.bounds_arrays(prob)
+    for extra in (dict(max_iter=8, abs_pri_tol=0.0, abs_dua_tol=0.0), dict(max_iter=60)):
+        settings = dict(O.DEFAULT_SETTINGS, **extra)
+        sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+        assert sol.kernel_name().startswith("stream<"), sol.kernel_name()
+        sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
+        sol.solve()
+        got = sol.get_state()
+        st = O.new_state(B, nx, nu, N); st["x"][:, 0] = x0
+        O.Oracle(prob, np.float32, settings, allow_unpinned_dims=True).solve(st, *bnds, xref, nthreads=8)
+        if extra["max_iter"] == 8:
+            assert np.array_equal(got["iter"], st["iter"]) and np.array_equal(got["status"], st["status"])
+            for k in ("x", "u", "d", "p", "y", "g"):
+                scale = max(float(np.abs(st[k]).max()), 1e-2)
+                err = float(np.abs(got[k].astype(np.float64) - st[k]).max()) / scale
+                assert err <= 2e-4, f"{dims} {k}: {err:.2e}"
+        else:
+            same = got["status"] == st["status"]
+            assert same.mean() >= 0.9, (dims, same.mean())
+            assert np.abs(got["iter"][same].astype(int) - st["iter"][same]).max() <= 6
+        sol.close()
+    with pytest.raises(tinympc.TinyBatchError):
+        tinympc.TinyBatchSolver(pr.random_system(68, 4, 5, seed=1), 4)   # nx > 64: no kernel at all, refused at create
 
 
 @pytest.mark.parametrize("variant_name", ["row_exact", "row_fast", "loop_exact", "stream"])
