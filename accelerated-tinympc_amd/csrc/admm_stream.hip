@@ -265,6 +265,15 @@ __global__ __launch_bounds__(WAVE) void admm_stream_kernel(const SolveParams P)
     // For converged instances x and u are regenerated from the frozen d (the same instruction sequence as the
     // sweep that produced them => bit-identical) instead of being stored on every iteration.
     {
+        // A cold start (reset_workspace() folded into this launch: the arrays still hold the previous solve) that converged in
+        // its FIRST iteration ran no backward sweep, which is what writes p, d, v, z: for such an instance they are the zeros
+        // the workspace was reset to — d reads as zero below and the four arrays are materialised here.
+        const bool fresh = valid && (P.cold_start != 0) && st == TINY_STATUS_SOLVED_ && itn == 1;
+        float zx[NXC], zu[NUC];
+#pragma unroll
+        for (int k = 0; k < NXC; k++) zx[k] = 0.f;
+#pragma unroll
+        for (int m = 0; m < NUC; m++) zu[m] = 0.f;
         float xs[NXC];
 #pragma unroll
         for (int k = 0; k < NXC; k++) xs[k] = x0[k];
@@ -272,6 +281,8 @@ __global__ __launch_bounds__(WAVE) void admm_stream_kernel(const SolveParams P)
         {
             const size_t xo = xbase + (size_t)i * xstep;
             float g[NXC], vn[NXC], xr[NXC], q[NXC];
+            stv<NXC>(P.v + xo, zx, fresh);
+            if (i < N - 1) stv<NXC>(P.p + xo, zx, fresh);
             ldv<NXC>(P.g + xo, g);
             ldv<NXC>(P.vnew + xo, vn);
             load_xref(i, xr);
@@ -288,6 +299,10 @@ __global__ __launch_bounds__(WAVE) void admm_stream_kernel(const SolveParams P)
                 const size_t uo = ubase + (size_t)i * ustep;
                 float dd[NUC], us[NUC], xn[NXC], y[NUC], zn[NUC], r[NUC];
                 ldv<NUC>(P.d + uo, dd);
+#pragma unroll
+                for (int m = 0; m < NUC; m++) dd[m] = fresh ? 0.f : dd[m];
+                stv<NUC>(P.d + uo, zu, fresh);
+                stv<NUC>(P.z + uo, zu, fresh);
                 ldv<NUC>(P.y + uo, y);
                 ldv<NUC>(P.znew + uo, zn);
                 lqr_step<D>(op, xs, dd, us, xn);

@@ -874,10 +874,10 @@ int prepare_solve(TinyBatch *tb, int *variant)
     }
     TRY(flush_x0_zero(tb)); // every solve reads x.col(0)
     if (tb->max_iter <= 0) TRY(flush_pending(tb));
-    // The kernels that stream their state through HBM write p, d, v, z only in backward sweeps: a cold start that
-    // converges in its first iteration (x0 at the origin) would leave those arrays unmaterialised.  Only the
-    // register-resident kernels fold reset_workspace() into the solve; for the others the zeros are written now.
-    if (tb->cold_pending && (v == VAR_STREAM || row_family(tb) == 2 || row_family(tb) == 3)) TRY(flush_pending(tb));
+    // A cold start that converges in its first iteration (x0 at the origin) runs no backward sweep, which is what writes p, d, v, z.
+    // reset_workspace() is folded into the launch by the kernels that handle a cold start themselves; the two that stream the
+    // row layout through HBM (rowstream, wavestream) write p, d, v, z only in backward sweeps and get the zeros materialised
+    if (tb->cold_pending && v != VAR_STREAM && (row_family(tb) == 2 || row_family(tb) == 3)) TRY(flush_pending(tb));
     update_kname(tb);
     *variant = v;
     return 0;
