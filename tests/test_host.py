@@ -217,10 +217,20 @@ def test_native_names_header_is_plain_c_and_matches_the_binding(tinympc, tmp_pat
         assert [f[0] for f in native.TinyWorkspace._fields_[3:]] == ref_members
 
 
-def test_recorded_bench_line_has_the_contract_fields():
-    """profiles/r01_bench_default_line.json is the stdout of `python bench.py` on the MI355X: the keys the driver reads."""
+@pytest.mark.parametrize("name", ["r01_bench_default_line.json", "r02_bench_default_line_c.json", "r02_bench_random32_line_b.json"])
+def test_recorded_bench_line_has_the_contract_fields(name):
+    """profiles/*_bench_*_line*.json are the stdout of `python bench.py [--config random32]` on the MI355X: the keys the driver reads."""
     import json
-    d = json.loads((ROOT / "profiles" / "r01_bench_default_line.json").read_text())
+    d = json.loads((ROOT / "profiles" / name).read_text())
+    if name.startswith("r02"):   # round 2 made the line self-describing
+        assert d["config"]["world_size_seen"] == d["n_gpus"] and "backend" in d["config"] and d["config"]["instances_total"] > 0
+        assert d["parity"]["bitwise_u"] is True and d["parity"]["iter_mismatch"] == 0 and d["parity"]["status_mismatch"] == 0
+        kk = d["roofline"]["kernel_ms_per_step"]
+        assert kk["min"] <= kk["median"] <= kk["max"] and kk["n"] >= 5
+        assert d["roofline"]["kernel"].endswith("exact>")   # the exact kernel is the one `value` is measured on
+    if "random32" in name:
+        assert d["scaling"] == "strong" and d["config"]["nx"] == 32
+        d = dict(d, scaling="weak")   # the remaining checks are shared with the weak-scaling default line
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
