@@ -6,8 +6,12 @@
 //       -Wl,-rpath,$PWD/accelerated-tinympc_amd/lib -o build/quadrotor_hovering_native
 //   ./build/quadrotor_hovering_native accelerated-tinympc_amd/data/quadrotor_20hz.bin
 //
-// What changes for a maintainer porting the reference example: Eigen members become float arrays (column-major, which
-// is what Eigen stores), `work.x.col(0) = x0` becomes a copy into the first nx floats, and NSTATES/NINPUTS/NHORIZON are
+// The same file builds the reference as it is checked in (typedef double tinytype, NHORIZON 10, glob_opts.hpp:3-7):
+//   g++ -std=c++17 -O2 -DTINYMPC_TINYTYPE_DOUBLE -Iinclude examples/quadrotor_hovering_native.cpp -Laccelerated-tinympc_amd/lib
+//       -ltinympc_wrapper64 -Wl,-rpath,$PWD/accelerated-tinympc_amd/lib -o build/quadrotor_hovering_native64
+//
+// What changes for a maintainer porting the reference example: Eigen members become tinytype arrays (column-major, which
+// is what Eigen stores), `work.x.col(0) = x0` becomes a copy into the first nx elements, and NSTATES/NINPUTS/NHORIZON are
 // fields of the workspace.  Prints the same tracking-error line per step as the reference (hovering.cpp:98).
 #include "tinympc_admm.h"
 
@@ -15,13 +19,17 @@
 #include <cstdio>
 #include <vector>
 
-static constexpr int NSTATES = 12, NINPUTS = 4, NHORIZON = 30, NTOTAL = 70;
+#ifdef TINYMPC_TINYTYPE_DOUBLE
+static constexpr int NSTATES = 12, NINPUTS = 4, NHORIZON = 10, NTOTAL = 70; // glob_opts.hpp:5-9 as checked in
+#else
+static constexpr int NSTATES = 12, NINPUTS = 4, NHORIZON = 30, NTOTAL = 70; // the horizon the code generator is run with
+#endif
 
-static std::vector<float> colmajor(const double *rm, int rows, int cols)
+static std::vector<tinytype> colmajor(const double *rm, int rows, int cols)
 {
-    std::vector<float> cm((size_t)rows * cols);
+    std::vector<tinytype> cm((size_t)rows * cols);
     for (int i = 0; i < rows; i++)
-        for (int j = 0; j < cols; j++) cm[(size_t)j * rows + i] = (float)rm[(size_t)i * cols + j];
+        for (int j = 0; j < cols; j++) cm[(size_t)j * rows + i] = (tinytype)rm[(size_t)i * cols + j];
     return cm;
 }
 
@@ -35,21 +43,21 @@ int main(int argc, char **argv)
     if (!f || std::fread(raw.data(), sizeof(double), ndbl, f) != ndbl) { std::fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
     std::fclose(f);
     const double *p = raw.data();
-    const float rho = (float)*p++;
+    const tinytype rho = (tinytype)*p++;
     auto Adyn = colmajor(p, NSTATES, NSTATES); p += NSTATES * NSTATES;
     auto Bdyn = colmajor(p, NSTATES, NINPUTS); p += NSTATES * NINPUTS;
     auto Kinf = colmajor(p, NINPUTS, NSTATES); p += NINPUTS * NSTATES;
     auto Pinf = colmajor(p, NSTATES, NSTATES); p += NSTATES * NSTATES;
     auto Quu_inv = colmajor(p, NINPUTS, NINPUTS); p += NINPUTS * NINPUTS;
     auto AmBKt = colmajor(p, NSTATES, NSTATES); p += NSTATES * NSTATES;
-    std::vector<float> Q(p, p + NSTATES);
+    std::vector<tinytype> Q(p, p + NSTATES);
 
     // hovering.cpp:25-28: the four structs are the caller's
     TinyCache cache{rho, Kinf.data(), Pinf.data(), Quu_inv.data(), AmBKt.data(), nullptr};
-    TinySettings settings{1e-3f, 1e-3f, 100, 1, 1, 1}; // :73-78
+    TinySettings settings{(tinytype)1e-3, (tinytype)1e-3, 100, 1, 1, 1}; // :73-78
     const size_t nxN = (size_t)NSTATES * NHORIZON, nuN = (size_t)NINPUTS * (NHORIZON - 1);
-    std::vector<float> x(nxN), q(nxN), pp(nxN), v(nxN), vnew(nxN), g(nxN), u(nuN), r(nuN), d(nuN), z(nuN), znew(nuN), y(nuN);
-    std::vector<float> u_min(nuN, -0.5f), u_max(nuN, 0.5f), x_min(nxN, -5.f), x_max(nxN, 5.f), Xref(nxN, 0.f); // :44-47
+    std::vector<tinytype> x(nxN), q(nxN), pp(nxN), v(nxN), vnew(nxN), g(nxN), u(nuN), r(nuN), d(nuN), z(nuN), znew(nuN), y(nuN);
+    std::vector<tinytype> u_min(nuN, -0.5), u_max(nuN, 0.5), x_min(nxN, -5), x_max(nxN, 5), Xref(nxN, 0); // :44-47
     TinyWorkspace work{};
     work.nx = NSTATES; work.nu = NINPUTS; work.N = NHORIZON;
     work.x = x.data(); work.u = u.data(); work.q = q.data(); work.r = r.data(); work.p = pp.data(); work.d = d.data();
@@ -58,10 +66,10 @@ int main(int argc, char **argv)
     work.u_min = u_min.data(); work.u_max = u_max.data(); work.x_min = x_min.data(); work.x_max = x_max.data(); work.Xref = Xref.data();
     TinySolver solver{&settings, &cache, &work};
 
-    const float Xref_origin[NSTATES] = {0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // :83-85
+    const tinytype Xref_origin[NSTATES] = {0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // :83-85
     for (int j = 0; j < NHORIZON; j++)
         for (int i = 0; i < NSTATES; i++) Xref[(size_t)j * NSTATES + i] = Xref_origin[i];
-    float x0[NSTATES] = {0, 1, 0, 0.1f, 0, 0, 0, 0, 0, 0, 0, 0}; // :88
+    tinytype x0[NSTATES] = {0, 1, 0, (tinytype)0.2, 0, 0, (tinytype)0.1, 0, 0, 0, 0, 0}; // :88
 
     for (int k = 0; k < NTOTAL; ++k)
     {
@@ -69,14 +77,14 @@ int main(int argc, char **argv)
         for (int i = 0; i < NSTATES; i++) err += (double)(x0[i] - Xref[i]) * (x0[i] - Xref[i]);
         std::printf("tracking error at step %2d: %.4f\n", k, std::sqrt(err)); // :98
         for (int i = 0; i < NSTATES; i++) x[i] = x0[i];                         // :95  work->x.col(0) = x0
-        for (auto &e : y) e = 0.f;                                              // :100
-        for (auto &e : g) e = 0.f;                                              // :101
+        for (auto &e : y) e = 0;                                              // :100
+        for (auto &e : g) e = 0;                                              // :101
         const int rc = tiny_solve(&solver);                                     // :104
         if (rc < 0) { std::fprintf(stderr, "tiny_solve failed (%d)\n", rc); return 1; }
-        float xn[NSTATES];                                                      // :110  x0 = Adyn*x0 + Bdyn*u.col(0)
+        tinytype xn[NSTATES];                                                      // :110  x0 = Adyn*x0 + Bdyn*u.col(0)
         for (int i = 0; i < NSTATES; i++)
         {
-            float a = 0.f, b = 0.f;
+            tinytype a = 0, b = 0;
             for (int kk = 0; kk < NSTATES; kk++) a += Adyn[(size_t)kk * NSTATES + i] * x0[kk];
             for (int m = 0; m < NINPUTS; m++) b += Bdyn[(size_t)m * NSTATES + i] * u[m];
             xn[i] = a + b;

@@ -128,6 +128,11 @@ def test_cpp_example_compiles_and_links_against_the_c_abi(tinympc, tmp_path):
                         str(ROOT / "examples" / "quadrotor_hovering_native.cpp"), f"-L{lib_dir}", "-ltinympc_wrapper",
                         f"-Wl,-rpath,{lib_dir}", "-o", str(tmp_path / "hover_native")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    # ... and, as the reference is checked in (typedef double tinytype, N = 10), against the double build of the same names
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-DTINYMPC_TINYTYPE_DOUBLE", f"-I{ROOT / 'include'}",
+                        str(ROOT / "examples" / "quadrotor_hovering_native.cpp"), f"-L{lib_dir}", "-ltinympc_wrapper64",
+                        f"-Wl,-rpath,{lib_dir}", "-o", str(tmp_path / "hover_native64")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
 
 
 WRAPPER_SYMBOLS = ["set_x0", "set_xref", "set_umin", "set_umax", "set_xmin", "set_xmax", "reset_dual_variables",

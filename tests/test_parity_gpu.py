@@ -671,6 +671,34 @@ def test_reference_wrapper_names_drive_the_hovering_loop():
     lib.tiny_wrapper_teardown()
 
 
+@pytest.mark.parametrize("double", [False, True])
+def test_cpp_hovering_example_runs_against_the_native_names(tinympc, tmp_path, double):
+    """examples/quadrotor_hovering_native.cpp — the reference's hovering example written against include/tinympc_admm.h — built
+    with g++ for float (libtinympc_wrapper.so, N = 30) and, as the reference is checked in, for double (libtinympc_wrapper64.so,
+    N = 10): 70 closed-loop steps through tiny_solve(&solver), the tracking error shrinks to the hover point and the last solve
+    converges in the iteration count of the compiled reference's own run."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    if shutil.which("g++") is None:
+        pytest.skip("no g++ on this box")
+    root = Path(__file__).resolve().parents[1]
+    lib_dir = root / "accelerated-tinympc_amd" / "lib"
+    exe = tmp_path / ("hover64" if double else "hover32")
+    cmd = ["g++", "-std=c++17", "-O1", f"-I{root / 'include'}", str(root / "examples" / "quadrotor_hovering_native.cpp"), f"-L{lib_dir}",
+           "-ltinympc_wrapper64" if double else "-ltinympc_wrapper", f"-Wl,-rpath,{lib_dir}", "-o", str(exe)]
+    if double:
+        cmd.insert(1, "-DTINYMPC_TINYTYPE_DOUBLE")
+    subprocess.run(cmd, check=True)
+    r = subprocess.run([str(exe), str(root / "accelerated-tinympc_amd" / "data" / "quadrotor_20hz.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    errs = [float(l.split(":")[1]) for l in lines if l.startswith("tracking error")]
+    assert len(errs) == 70 and errs[0] > 2.0 and errs[-1] < 0.02 and errs[-1] < errs[35] < errs[0]
+    _, _, _, z = load_fixture("quad_hover_f64_N10" if double else "quad_hover_f32_N30")
+    assert lines[-1] == f"final: iter={int(z['trace_iter'][69])} status=1", lines[-1]
+
+
 def test_native_names_tiny_solve_hovering_loop(tinympc):
     """examples/quadrotor_hovering.cpp:90-114 written against include/tinympc_admm.h (TinySolver{settings,cache,work},
     tiny_solve): the caller owns the workspace arrays, warm start travels through them like in the reference.  Controls,
