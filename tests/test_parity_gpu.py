@@ -699,6 +699,27 @@ def test_cpp_hovering_example_runs_against_the_native_names(tinympc, tmp_path, d
     assert lines[-1] == f"final: iter={int(z['trace_iter'][69])} status=1", lines[-1]
 
 
+def test_cpp_batched_tracking_example_runs(tinympc, tmp_path):
+    """examples/quadrotor_tracking_batched.cpp (nothing but include/tinympc_batch.h) built with g++ and run: 512 quadrotors track
+    the trajectory in closed loop on the exact register-resident kernel, the tracking error falls."""
+    import re
+    import shutil
+    import subprocess
+    from pathlib import Path
+    if shutil.which("g++") is None:
+        pytest.skip("no g++ on this box")
+    root = Path(__file__).resolve().parents[1]
+    lib_dir = root / "accelerated-tinympc_amd" / "lib"
+    exe = tmp_path / "track"
+    subprocess.run(["g++", "-std=c++17", "-O1", f"-I{root / 'include'}", str(root / "examples" / "quadrotor_tracking_batched.cpp"), f"-L{lib_dir}",
+                    "-ltinympc_hip", f"-Wl,-rpath,{lib_dir}", "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe), str(root / "accelerated-tinympc_amd" / "data" / "quadrotor_20hz.bin"), "512", "40"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "kernel: rowlane<12,4,30,exact>, 512 instances" in r.stdout, r.stdout[:300]
+    errs = [float(m) for m in re.findall(r"mean tracking error ([0-9.eE+-]+)", r.stdout)]
+    assert len(errs) >= 5 and all(np.isfinite(errs)) and errs[-1] <= errs[0]
+
+
 def test_native_names_tiny_solve_hovering_loop(tinympc):
     """examples/quadrotor_hovering.cpp:90-114 written against include/tinympc_admm.h (TinySolver{settings,cache,work},
     tiny_solve): the caller owns the workspace arrays, warm start travels through them like in the reference.  Controls,
