@@ -264,13 +264,21 @@ __global__ __launch_bounds__(WAVE) void admm_rowstream_kernel(const RowParams P)
     {
         // live-out: q, r (admm.cpp:80-82) and, for converged instances, x,u regenerated from the frozen d
         const bool solved = (st == TINY_STATUS_SOLVED_);
+        // reset_workspace() folded into this launch (cold start): an instance that converged in its FIRST iteration ran no
+        // backward sweep, which is what writes [p;d] and [v;z] — they are the zeros of the reset, materialised here
+        const bool fresh = valid && (P.cold_start != 0) && solved && itn == 1;
         float s = x0;
         for (int i = 0; i < N; i++)
         {
             const int o = rowbase + i * 16;
             float sv, xn = 0.f;
-            if (i < N - 1) lqr_step<NX, NU, EXACT, H16>(G, is_x, is_u, s, ldw<H16>(P.pd, o), sv, xn);
+            if (i < N - 1) lqr_step<NX, NU, EXACT, H16>(G, is_x, is_u, s, fresh ? 0.f : ldw<H16>(P.pd, o), sv, xn);
             else sv = is_x ? s : 0.f;
+            if (fresh)
+            {
+                if (i < N - 1) stw<H16>(P.pd, o, 0.f);
+                stw<H16>(P.vz, o, 0.f);
+            }
             if (valid && solved) stw<H16>(P.xu, o, sv);
             s = xn;
             const float cq = cost_of<H16>(P, is_x, is_u, xref_at(i), qrow, rrow, uref_off + i * 16);

@@ -180,13 +180,21 @@ __global__ __launch_bounds__(WAVE, WPS) void admm_wavestream_kernel(const RowPar
     {
         // live-out: q, r (admm.cpp:80-82) and, for a converged instance, x,u regenerated from the d it converged with
         const bool solved = (st == TINY_STATUS_SOLVED_);
+        // reset_workspace() folded into this launch (cold start): an instance that converged in its FIRST iteration ran no
+        // backward sweep, which is what writes [p;d] and [v;z] — they are the zeros of the reset, materialised here
+        const bool fresh = (P.cold_start != 0) && solved && itn == 1;
         float s = x0;
         for (int i = 0; i < N; i++)
         {
             const int o = rowbase + i * WAVE;
             float sv, xn = 0.f;
-            if (i < N - 1) wave_lqr_step<NX, NU>(G, vec, lane, is_x, is_u, s, P.pd[o], sv, xn);
+            if (i < N - 1) wave_lqr_step<NX, NU>(G, vec, lane, is_x, is_u, s, fresh ? 0.f : P.pd[o], sv, xn);
             else sv = is_x ? s : 0.f;
+            if (fresh)
+            {
+                if (i < N - 1) P.pd[o] = 0.f;
+                P.vz[o] = 0.f;
+            }
             if (solved) P.xu[o] = sv;
             s = xn;
             const float cq = is_x ? -(xref_at(i) * qrow) : -0.f; // -0: r = -rho*(znew - y) keeps the sign of a zero difference

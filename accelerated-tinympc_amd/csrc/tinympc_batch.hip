@@ -875,9 +875,9 @@ int prepare_solve(TinyBatch *tb, int *variant)
     TRY(flush_x0_zero(tb)); // every solve reads x.col(0)
     if (tb->max_iter <= 0) TRY(flush_pending(tb));
     // A cold start that converges in its first iteration (x0 at the origin) runs no backward sweep, which is what writes p, d, v, z.
-    // reset_workspace() is folded into the launch by the kernels that handle a cold start themselves; the two that stream the
-    // row layout through HBM (rowstream, wavestream) write p, d, v, z only in backward sweeps and get the zeros materialised
-    if (tb->cold_pending && v != VAR_STREAM && (row_family(tb) == 2 || row_family(tb) == 3)) TRY(flush_pending(tb));
+    // reset_workspace() is folded into the launch by every fused kernel: the register-resident ones start from zero registers,
+    // the streaming ones (MFMA, rowstream, wavestream) read zeros in their first iteration and zero-fill p, d, v, z of such an
+    // instance in their epilogue
     update_kname(tb);
     *variant = v;
     return 0;
