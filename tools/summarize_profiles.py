@@ -86,3 +86,31 @@ if line:
         table[f"{label(k)}:early_exit:{line['config']['instances_per_gpu']}"] = {"bytes": d["hbm_bytes"], "csrc_sha": kernel_source_sha(), "profile": tag}
 tf.write_text(json.dumps(table, indent=1))
 print(json.dumps({k: v for k, v in out.items() if k != "bench_line_under_profiler"}, indent=1)[:3000])
+
+
+# ---- instruction-issue counters (tools/collect_issue_counters.sh -> gpurun_out/issue_<tag>/) -> profiles/<tag>_rowlane_issue_counters.json
+import collections, csv as _csv, glob as _glob
+issue = {}
+for f in _glob.glob(str(ROOT / "gpurun_out" / f"issue_{tag}" / "*" / "*" / "*counter_collection.csv")):
+    per = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
+    for r in _csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "admm_" not in k: continue
+        per[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k].add(r["Dispatch_Id"])
+    for k in per:
+        issue.setdefault(k, {}).update({c: v / len(cnt[k]) for c, v in per[k].items()})
+if issue:
+    dst = prof / f"{tag}_rowlane_issue_counters.json"
+    note = json.loads(dst.read_text()).get("note", "") if dst.exists() else ""
+    res = {"note": note or "rocprofv3 --pmc passes of tools/collect_issue_counters.sh over the default bench run; averages per launch; "
+                          "SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count in units of 4 shader clocks", "kernels": {}}
+    for k, d in issue.items():
+        dd = dict(d)
+        if all(c in d for c in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_INSTS_SALU", "SQ_INSTS_LDS")):
+            waves = 16384.0  # 65 536 instances, four per wave
+            dd["derived"] = {"valu_per_wave": d["SQ_INSTS_VALU"] / waves, "salu_per_wave": d["SQ_INSTS_SALU"] / waves, "lds_per_wave": d["SQ_INSTS_LDS"] / waves,
+                             "clocks_per_valu_per_simd": 4 * d["SQ_WAVE_CYCLES"] / 2 / d["SQ_INSTS_VALU"],
+                             "wait_inst_any_frac_of_wave_cycles": d.get("SQ_WAIT_INST_ANY", 0.0) / d["SQ_WAVE_CYCLES"]}
+            if d.get("SQC_ICACHE_REQ"): dd["derived"]["icache_miss_rate"] = d.get("SQC_ICACHE_MISSES", 0.0) / d["SQC_ICACHE_REQ"]
+        res["kernels"][k] = dd
+    dst.write_text(json.dumps(res, indent=1))
