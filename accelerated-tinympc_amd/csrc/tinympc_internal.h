@@ -140,7 +140,7 @@ bool tile16_supported(int nx, int nu, int N);
 hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t stream);
 
 // wave-per-instance exact kernel (admm_wave.hip): 16 < nx + nu <= 64, any N, state in HBM, row width 64
-#define TINY_FOR_EACH_WAVEDIMS(X) X(32, 16) X(16, 8) X(16, 4)
+#define TINY_FOR_EACH_WAVEDIMS(X) X(32, 16) X(16, 8) X(16, 4) X(20, 8) X(24, 4)
 bool wavedims_supported(int nx, int nu);
 hipError_t launch_admm_wavestream(int nx, int nu, const RowParams &P, hipStream_t stream);
 // the same classes with the loop-carried state on chip (admm_waveres.hip): N <= 50

@@ -64,7 +64,7 @@ extern "C"
      * (types.hpp:26-107, quadrotor_hovering.cpp:25-28).
      * Dimensions (glob_opts.hpp:5-7 fixes them at compile time; here they are arguments): any nx <= 64, nu <= 32, N >= 2.
      * Classes with a compiled exact kernel — (nx, nu) = (12,4), (4,1), (8,3), (8,4), (12,2), (4,2), (4,4), (32,16), (16,8),
-     * (16,4) — compute bitwise what the reference computes; any other class runs in fma arithmetic on the MFMA streaming
+     * (16,4), (20,8), (24,4) — compute bitwise what the reference computes; any other class runs in fma arithmetic on the MFMA streaming
      * kernel (tiny_batch_kernel_name reports "stream<...>").  Beyond those limits: TINY_BATCH_EUNSUPPORTED. */
     int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int device);
     void tiny_batch_destroy(TinyBatch *tb);

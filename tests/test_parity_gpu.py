@@ -1090,7 +1090,7 @@ def test_wave_kernel_vs_oracle(tinympc, oracle_mod, B, wave_kernel):
         sol.close()
 
 
-@pytest.mark.parametrize("dims", [(32, 16, 50), (16, 8, 49), (16, 4, 33)])
+@pytest.mark.parametrize("dims", [(32, 16, 50), (16, 8, 49), (16, 4, 33), (20, 8, 21)])
 def test_wave_kernel_fma_arithmetic(tinympc, oracle_mod, dims):
     """fma arithmetic of the state-on-chip wave kernel (waveres<...,fast>): held to the bar of every other fma variant —
     iteration counts and arrays within the reference's own fp64-vs-fp32 spread (compare_states) — over a warm-started
@@ -1123,7 +1123,7 @@ def test_wave_kernel_fma_arithmetic(tinympc, oracle_mod, dims):
         sol.close()
 
 
-@pytest.mark.parametrize("dims", [(20, 8, 12), (6, 2, 9), (30, 10, 7), (5, 5, 8), (3, 2, 6), (10, 3, 11), (40, 12, 6), (64, 32, 4), (33, 17, 5)])
+@pytest.mark.parametrize("dims", [(20, 12, 12), (6, 2, 9), (30, 10, 7), (5, 5, 8), (3, 2, 6), (10, 3, 11), (40, 12, 6), (64, 32, 4), (33, 17, 5)])
 def test_classes_without_an_instantiation_run_on_the_padded_mfma_kernel(tinympc, oracle_mod, dims):
     """The reference takes any NSTATES / NINPUTS / NHORIZON (glob_opts.hpp:5-7).  A class with no compiled exact kernel is
     served, in fma arithmetic, by the smallest MFMA streaming instantiation that contains it (any nx <= 64, nu <= 32, any N):
@@ -1424,10 +1424,10 @@ def test_randomised_differential_tools_short_run(tool):
     assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("dims", [(16, 8, 10), (16, 4, 12), (16, 4, 33), (16, 8, 49), (16, 4, 60)])
+@pytest.mark.parametrize("dims", [(16, 8, 10), (16, 4, 12), (16, 4, 33), (16, 8, 49), (16, 4, 60), (20, 8, 10), (20, 8, 37), (24, 4, 10), (24, 4, 55)])
 def test_wave_kernel_other_classes(tinympc, oracle_mod, dims):
-    """Two more classes of the wave-per-instance kernel, each pinned against its own reference build in test_oracle.py:
-    (16,8) takes Eigen's GEMV path like (32,16), (16,4) does not.  Horizons on both sides of the register vectors' 32- and
+    """Four more classes of the wave-per-instance kernel, each pinned against its own reference build in test_oracle.py:
+    (16,8) and (20,8) take Eigen's GEMV path like (32,16), (16,4) and (24,4) do not.  Horizons on both sides of the register vectors' 32- and
     48-step seams of the state-on-chip kernel, and one beyond its 50 steps (streaming kernel)."""
     O, pr = oracle_mod, tinympc.problems
     nx, nu, N = dims
