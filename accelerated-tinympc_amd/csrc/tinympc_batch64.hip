@@ -345,6 +345,9 @@ __device__ __forceinline__ double lazy_sum(const double (&t)[CNT])
     else return novec_sum(t);
 }
 
+// problem classes of the fp64 library (the thread-per-instance kernels; any N).  nx and nu must each be <= 2 or even (the
+// reference's order for other sizes depends on alignment, see row_dot) and not both >= 8 (Eigen's GEMV kernel is not restated here)
+#define TINY_FOR_EACH_F64DIMS(X) X(12, 4) X(4, 1) X(8, 4) X(12, 2) X(4, 2) X(4, 4) X(16, 4)
 #define TINY_FOR_EACH_F64ROWS(X) X(12, 4, 10) X(12, 4, 30) X(12, 4, 20) X(4, 1, 10) X(8, 4, 9)
 constexpr int F64_AHEAD = 4; // bounds are fetched this many steps ahead of their use
 
@@ -958,9 +961,9 @@ int run_step64(TinyBatch64 *tb, int *conv_dev)
     int rc = prepare64(tb, P);
     if (rc < 0) return rc;
     const int nblocks = tb->bpad / WAVE64;
-    if (tb->nx == 12 && tb->nu == 4) hipLaunchKernelGGL((admm_f64_step_kernel<12, 4, FN>), dim3(nblocks), dim3(WAVE64), 0, 0, P, conv_dev);
-    else if (tb->nx == 4 && tb->nu == 1) hipLaunchKernelGGL((admm_f64_step_kernel<4, 1, FN>), dim3(nblocks), dim3(WAVE64), 0, 0, P, conv_dev);
-    else hipLaunchKernelGGL((admm_f64_step_kernel<8, 4, FN>), dim3(nblocks), dim3(WAVE64), 0, 0, P, conv_dev);
+#define TINY_F64_STEP_LAUNCH(NX, NU) \
+    if (tb->nx == NX && tb->nu == NU) hipLaunchKernelGGL((admm_f64_step_kernel<NX, NU, FN>), dim3(nblocks), dim3(WAVE64), 0, 0, P, conv_dev);
+    TINY_FOR_EACH_F64DIMS(TINY_F64_STEP_LAUNCH)
     HIP64(hipGetLastError());
     HIP64(hipDeviceSynchronize());
     return 0;
@@ -976,8 +979,11 @@ int tiny_batch64_create(TinyBatch64 **out, int nx, int nu, int N, int batch, int
     CHECK64(out, "NULL out pointer");
     *out = nullptr;
     CHECK64(nx >= 1 && nu >= 1 && N >= 2 && batch >= 1, "need nx>=1, nu>=1, N>=2, batch>=1 (got %d,%d,%d,%d)", nx, nu, N, batch);
-    if (!((nx == 12 && nu == 4) || (nx == 4 && nu == 1) || (nx == 8 && nu == 4)))
-        return fail64(TINY_BATCH_EUNSUPPORTED, "no fp64 kernel instantiation for nx=%d nu=%d (compiled: (12,4), (4,1), (8,4))", nx, nu);
+    bool have = false;
+#define TINY_F64_HAVE(NX, NU) have = have || (nx == NX && nu == NU);
+    TINY_FOR_EACH_F64DIMS(TINY_F64_HAVE)
+    if (!have)
+        return fail64(TINY_BATCH_EUNSUPPORTED, "no fp64 kernel instantiation for nx=%d nu=%d (add it to TINY_FOR_EACH_F64DIMS)", nx, nu);
     int ndev = 0;
     HIP64(hipGetDeviceCount(&ndev));
     CHECK64(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
@@ -1122,9 +1128,12 @@ int tiny_batch64_solve(TinyBatch64 *tb)
         hipLaunchKernelGGL((admm_f64_rows_kernel<NX, NU, NN>), dim3(nrow_blocks), dim3(WAVE64), 0, 0, P, (const double *)tb->row_gains);
         TINY_FOR_EACH_F64ROWS(TINY_F64ROWS_LAUNCH)
     }
-    else if (tb->nx == 12 && tb->nu == 4) hipLaunchKernelGGL((admm_f64_kernel<12, 4>), dim3(nblocks), dim3(WAVE64), 0, 0, P);
-    else if (tb->nx == 4 && tb->nu == 1) hipLaunchKernelGGL((admm_f64_kernel<4, 1>), dim3(nblocks), dim3(WAVE64), 0, 0, P);
-    else hipLaunchKernelGGL((admm_f64_kernel<8, 4>), dim3(nblocks), dim3(WAVE64), 0, 0, P);
+    else
+    {
+#define TINY_F64_LAUNCH(NX, NU) \
+    if (tb->nx == NX && tb->nu == NU) hipLaunchKernelGGL((admm_f64_kernel<NX, NU>), dim3(nblocks), dim3(WAVE64), 0, 0, P);
+        TINY_FOR_EACH_F64DIMS(TINY_F64_LAUNCH)
+    }
     HIP64(hipGetLastError());
     int n = 0;
     HIP64(hipMemcpy(&n, tb->n_unsolved, sizeof(int), hipMemcpyDeviceToHost));
@@ -1139,9 +1148,10 @@ int tiny_batch64_mpc_step(TinyBatch64 *tb)
     rc = tiny_batch64_solve(tb);                    // :104
     if (rc < 0) return rc;
     const int nb = (tb->batch + 127) / 128;          // :110-111
-    if (tb->nx == 12 && tb->nu == 4) hipLaunchKernelGGL((plant64_kernel<12, 4>), dim3(nb), dim3(128), 0, 0, tb->arr[TINY_ARR_X], tb->arr[TINY_ARR_U], tb->mats, tb->batch, tb->bpad);
-    else if (tb->nx == 4 && tb->nu == 1) hipLaunchKernelGGL((plant64_kernel<4, 1>), dim3(nb), dim3(128), 0, 0, tb->arr[TINY_ARR_X], tb->arr[TINY_ARR_U], tb->mats, tb->batch, tb->bpad);
-    else hipLaunchKernelGGL((plant64_kernel<8, 4>), dim3(nb), dim3(128), 0, 0, tb->arr[TINY_ARR_X], tb->arr[TINY_ARR_U], tb->mats, tb->batch, tb->bpad);
+#define TINY_F64_PLANT(NX, NU)                                                                                                       \
+    if (tb->nx == NX && tb->nu == NU)                                                                                                \
+        hipLaunchKernelGGL((plant64_kernel<NX, NU>), dim3(nb), dim3(128), 0, 0, tb->arr[TINY_ARR_X], tb->arr[TINY_ARR_U], tb->mats, tb->batch, tb->bpad);
+    TINY_FOR_EACH_F64DIMS(TINY_F64_PLANT)
     HIP64(hipGetLastError());
     return rc;
 }

@@ -20,14 +20,14 @@ from oracle import oracle as O  # noqa: E402
 pr = T.problems
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-CLASSES = [("quad", 10), ("quad", 30), ("quad", 20), ("quad", 7), ("quad", 41), ("cartpole", 10), ("cartpole", 3), ("cartpole", 33), ("r8_4", 9), ("r8_4", 26)]
+CLASSES = [("quad", 10), ("quad", 30), ("quad", 20), ("quad", 7), ("quad", 41), ("cartpole", 10), ("cartpole", 3), ("cartpole", 33), ("r8_4", 9), ("r8_4", 26), ("r12_2", 11), ("r4_2", 8), ("r4_4", 6), ("r16_4", 10)]
 t_end, rounds, solves, t_note, overflowed = time.time() + budget, 0, 0, time.time(), 0
 while time.time() < t_end:
     if time.time() - t_note > 45:
         print(f"... {rounds} rounds, {solves} solves so far", flush=True)
         t_note = time.time()
     kind, N = CLASSES[rng.integers(len(CLASSES))]
-    prob = {"quad": lambda: pr.quadrotor(20, N), "cartpole": lambda: pr.cartpole(N), "r8_4": lambda: pr.random_system(8, 4, N, seed=7)}[kind]()
+    prob = {"quad": lambda: pr.quadrotor(20, N), "cartpole": lambda: pr.cartpole(N), }.get(kind, lambda: pr.random_system(int(kind[1:].split("_")[0]), int(kind.split("_")[1]), N, seed=7))()
     nx, nu = prob["nx"], prob["nu"]
     B = int(rng.choice([1, 2, 3, 63, 64, 65, 200, 257]))
     settings = dict(abs_pri_tol=float(rng.choice([0.0, 1e-3, 1e-2, 0.5])), abs_dua_tol=float(rng.choice([0.0, 1e-3, 1e-1, 5.0])),

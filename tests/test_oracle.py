@@ -53,7 +53,8 @@ def test_max_iter_zero_touches_only_status_and_iter(oracle_mod):
 CFGS = [(np.float32, 12, 4, 30), (np.float64, 12, 4, 30), (np.float64, 12, 4, 10), (np.float32, 12, 4, 10),
         (np.float32, 4, 1, 10), (np.float64, 4, 1, 10), (np.float32, 8, 3, 7), (np.float32, 32, 16, 50),
         (np.float32, 8, 4, 9), (np.float32, 12, 2, 11), (np.float32, 4, 2, 8), (np.float32, 4, 4, 6), (np.float64, 8, 4, 9),
-        (np.float32, 16, 8, 10), (np.float32, 16, 4, 10), (np.float32, 20, 8, 10), (np.float32, 24, 4, 10)]
+        (np.float32, 16, 8, 10), (np.float32, 16, 4, 10), (np.float32, 20, 8, 10), (np.float32, 24, 4, 10),
+        (np.float64, 12, 2, 11), (np.float64, 4, 2, 8), (np.float64, 4, 4, 6), (np.float64, 16, 4, 10)]
 
 
 @pytest.mark.parametrize("dt,nx,nu,N", CFGS)

@@ -2151,8 +2151,11 @@ def test_fp64_device_closed_loop_vs_oracle(tinympc, oracle_mod, nx, nu, N):
     sol.close()
 
 
+F64_ROWS = {(12, 4, 10), (12, 4, 30), (12, 4, 20), (4, 1, 10), (8, 4, 9)}   # TINY_FOR_EACH_F64ROWS
+
+
 @pytest.mark.parametrize("kernel", [1, 2])
-@pytest.mark.parametrize("nx,nu,N", [(12, 4, 30), (12, 4, 10), (12, 4, 20), (4, 1, 10), (8, 4, 9), (12, 4, 13)])
+@pytest.mark.parametrize("nx,nu,N", [(12, 4, 30), (12, 4, 10), (12, 4, 20), (4, 1, 10), (8, 4, 9), (12, 4, 13), (12, 2, 11), (4, 2, 8), (4, 4, 6), (16, 4, 10)])
 def test_fp64_vs_oracle(tinympc, oracle_mod, nx, nu, N, kernel):
     """The fp64 library against the fp64 oracle (== the compiled reference's fp64 builds, tests/test_oracle.py) on random
     warm states with zeros and negative zeros: ragged batches, warm-started chain with dual resets, sparse termination
@@ -2183,10 +2186,10 @@ def test_fp64_vs_oracle(tinympc, oracle_mod, nx, nu, N, kernel):
         else:
             bnds, xref = shared, rng.standard_normal((N, nx)) * 0.2
         sol = tinympc.TinyBatchSolver64(prob, B, settings=settings)
-        if kernel == 2 and N == 13:   # no sixteen-lane instantiation for this horizon: refused, the thread kernel serves it
+        if kernel == 2 and (nx, nu, N) not in F64_ROWS:   # no sixteen-lane instantiation for this class / horizon: refused, the thread kernel serves it
             with pytest.raises(tinympc.TinyBatchError):
                 sol.select_kernel(2)
-            assert sol.kernel_name() == "thread64<12,4>"
+            assert sol.kernel_name() == f"thread64<{nx},{nu}>"
         else:
             sol.select_kernel(kernel)
         sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_state(st)
