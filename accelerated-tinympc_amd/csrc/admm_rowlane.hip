@@ -37,7 +37,7 @@ namespace tinympc
 #endif
 constexpr int BPI_AHEAD = TINY_BPI_AHEAD;
 template <int NX, int NU, int N, bool EXACT, bool H16, bool MPC = false, bool BPI = false, bool D32 = false>
-__global__ __launch_bounds__(WAVE, 2) void admm_rowlane_kernel(const RowParams P)
+__global__ __launch_bounds__(WAVE, (N > 32 && EXACT && !H16) ? 1 : 2) void admm_rowlane_kernel(const RowParams P)
 {
     constexpr bool HD = H16 && !D32; // storage precision of the duals (gy)
     const int lane = threadIdx.x;

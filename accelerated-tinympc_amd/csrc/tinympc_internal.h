@@ -72,7 +72,7 @@ struct SolveParams
 };
 
 // (nx, nu, N) triples with a compiled register-resident kernel (admm_rowlane.hip); needs nx + nu <= 16
-#define TINY_FOR_EACH_ROWLANE(X) X(12, 4, 30) X(12, 4, 25) X(12, 4, 20) X(12, 4, 10) X(4, 1, 10) X(8, 3, 7)
+#define TINY_FOR_EACH_ROWLANE(X) X(12, 4, 30) X(12, 4, 25) X(12, 4, 20) X(12, 4, 10) X(4, 1, 10) X(8, 3, 7) X(12, 4, 40) X(12, 4, 50)
 
 // "Row" layout used by the rowlane kernel: the twelve work arrays are stored as six stacked pairs
 //   xu = [x;u], qr = [q;r], pd = [p;d], vz = [v;z], vzn = [vnew;znew], gy = [g;y]
