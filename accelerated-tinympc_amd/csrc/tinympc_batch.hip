@@ -740,7 +740,7 @@ int resolve_variant(TinyBatch *tb, int *out)
 }
 
 // which of the three row kernels a row variant launches: 0 = unrolled register-resident (rowlane, fastest, one
-// instantiation per (nx, nu, N)), 1 = rolled-loop register-resident (rowloop, any N <= 32), 2 = any N with the state in
+// instantiation per (nx, nu, N)), 1 = rolled-loop register-resident (rowloop, any N <= 64), 2 = any N with the state in
 // HBM (rowstream).  tiny_batch_set_row_kernel() can force one of them.
 int row_family(const TinyBatch *tb)
 {

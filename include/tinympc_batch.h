@@ -181,8 +181,8 @@ extern "C"
      * every variant (per-instance bounds select the kernels that stream their state). */
     int tiny_batch_select_kernel(TinyBatch *tb, int variant);
     /* Which row kernel variants 2/3 (and auto) launch: 0 = auto (4 where it exists, else 1 where (nx,nu,N) has an unrolled
-     * instantiation, else 2 for N <= 32, else 3), 1 = rowlane (16 lanes per instance, unrolled, state in registers/LDS),
-     * 2 = rowloop (rolled loops, state in registers/LDS, any N <= 32), 3 = rowstream (any N, state in HBM),
+     * instantiation, else 2 for N <= 64, else 3), 1 = rowlane (16 lanes per instance, unrolled, state in registers/LDS),
+     * 2 = rowloop (rolled loops, state in registers/LDS, any N <= 64), 3 = rowstream (any N, state in HBM),
      * 4 = quadlane (4 lanes per instance, nx = 4 and nu = 1 only), 5 = tile16 (16 instances per wavefront as the columns of
      * a 16x16 MFMA tile, gain x state products on the matrix cores in both arithmetic modes, state in registers/LDS; nx = 12,
      * nu = 4 and an instantiated horizon; on request only; with a per-instance reference array or fp16 storage the handle

@@ -32,7 +32,7 @@ def dev_ints(a):
 pr = T.problems
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-CLASSES = [("quad", 30), ("quad", 25), ("quad", 20), ("quad", 10), ("quad", 17), ("quad", 7), ("quad", 36), ("quad", 40), ("quad", 50), ("cartpole", 10),
+CLASSES = [("quad", 30), ("quad", 25), ("quad", 20), ("quad", 10), ("quad", 17), ("quad", 7), ("quad", 36), ("quad", 40), ("quad", 50), ("quad", 61), ("quad", 67), ("cartpole", 10),
            ("cartpole", 23), ("odd", 7), ("odd", 13), ("rand32", 50), ("r8_4", 9), ("r12_2", 14), ("r4_2", 8), ("r4_4", 35), ("w16_8", 10), ("w16_4", 12), ("w20_8", 11), ("w24_4", 9)]
 t_end, rounds, solves, t_note, overflowed, refused = time.time() + budget, 0, 0, time.time(), 0, 0
 while time.time() < t_end:

@@ -558,13 +558,13 @@ def test_step_functions_individually(tinympc, oracle_mod, case, exact):
     sol.close()
 
 
-@pytest.mark.parametrize("case", [("quad", 5), ("quad", 17), ("quad", 20), ("quad", 25), ("quad", 32), ("quad", 33), ("quad", 45), ("quad", 40), ("quad", 50),
+@pytest.mark.parametrize("case", [("quad", 5), ("quad", 17), ("quad", 20), ("quad", 25), ("quad", 32), ("quad", 33), ("quad", 45), ("quad", 40), ("quad", 50), ("quad", 64), ("quad", 65),
                                   ("cartpole", 25), ("cartpole", 40), ("odd", 12), ("odd", 2),
                                   ("r8_4", 9), ("r8_4", 40), ("r12_2", 11), ("r4_2", 8), ("r4_4", 6)])  # classes pinned in test_oracle.py
 @pytest.mark.parametrize("variant_name", ["row_exact", "row_fast"])
 def test_any_horizon_row_kernel(tinympc, oracle_mod, case, variant_name):
-    """Horizons other than the examples' 10 and 30: a few have an unrolled instantiation (rowlane), otherwise N <= 32 runs on
-    the rolled-loop register-resident kernel (rowloop) and longer horizons on the any-N row kernel with the state in HBM
+    """Horizons other than the examples' 10 and 30: a few have an unrolled instantiation (rowlane), otherwise N <= 64 runs on
+    the rolled-loop register-resident kernels (rowloop) and longer horizons on the any-N row kernel with the state in HBM
     (rowstream); all stay bitwise in exact arithmetic.
     Cold start, then a warm start with reset duals; early exit."""
     O, pr = oracle_mod, tinympc.problems
@@ -585,7 +585,7 @@ def test_any_horizon_row_kernel(tinympc, oracle_mod, case, variant_name):
     settings = dict(O.DEFAULT_SETTINGS, max_iter=60)
     sol = make_solver(tinympc, prob, B, settings, xref, variant_name, bnds)
     unrolled = (kind, N) in (("quad", 20), ("quad", 25), ("quad", 40), ("quad", 50))  # TINY_FOR_EACH_ROWLANE
-    assert sol.kernel_name().startswith("rowlane" if unrolled else "rowloop" if N <= 32 else "rowstream"), sol.kernel_name()
+    assert sol.kernel_name().startswith("rowlane" if unrolled else "rowloop" if N <= 64 else "rowstream"), sol.kernel_name()
     orc = O.Oracle(prob, np.float32, settings)
     st = O.new_state(B, nx, nu, N)
     st["x"][:, 0] = x0
@@ -817,7 +817,7 @@ def test_native_names_step_functions(tinympc, oracle_mod, case):
 # (2^-10 = 9.8e-4 each, the "~1e-3" SURVEY.md expects), 4 x the fp16-storage-vs-fp32 spread of the same array).
 # The iteration-count drift against fp32 storage is reported by tools/bench_configs.py, not bounded here.
 # ---------------------------------------------------------------------------------------------------------------------
-H16_CASES = {"quad30": ("quad", 30), "quad17": ("quad", 17), "quad40": ("quad", 43), "cartpole10": ("cartpole", 10),
+H16_CASES = {"quad30": ("quad", 30), "quad17": ("quad", 17), "quad40": ("quad", 70), "cartpole10": ("cartpole", 10),
              "cartpole25": ("cartpole", 25)}  # rowlane, rowloop, rowstream, rowlane, rowloop
 
 
@@ -1324,7 +1324,7 @@ def test_kernel_selection_and_option_errors(tinympc):
         q17.set_dispatch(2)
     q17.set_dispatch(1)                                            # accepted everywhere, acts on large rowlane launches only
     q17.close()
-    q40 = tinympc.TinyBatchSolver(pr.quadrotor(20, 43), 8)         # N > 32 without an unrolled instantiation: only the streaming row kernel
+    q40 = tinympc.TinyBatchSolver(pr.quadrotor(20, 70), 8)         # N > 64: only the streaming row kernel
     assert q40.kernel_name().startswith("rowstream")
     with pytest.raises(tinympc.TinyBatchError):
         q40.set_row_kernel(2)
