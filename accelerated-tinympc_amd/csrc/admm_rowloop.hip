@@ -40,8 +40,14 @@ __global__ __launch_bounds__(WAVE, 3) void admm_rowloop_kernel(const RowParams P
 
     float2 *bnd = reinterpret_cast<float2 *>(lds); // [N][16] {lo, hi}, shared by the batch
     float *b = lds + N * 32 + lane;                 // b[i * WAVE]
-    for (int e = lane; e < N * 16; e += WAVE) bnd[e] = ld_bounds<H16>(P.bounds, e);
+    // batch-shared bounds are staged in LDS once; per-instance bounds (bounds_inst_stride != 0: a [B][N][16] table) are read
+    // from global memory one step ahead of their use
+    const bool bpi = P.bounds_inst_stride != 0;
+    const int bbase = inst_a * (int)P.bounds_inst_stride + r16;
+    if (!bpi)
+        for (int e = lane; e < N * 16; e += WAVE) bnd[e] = ld_bounds<H16>(P.bounds, e);
     __syncthreads();
+    auto bounds_at = [&](int i) { return bpi ? ld_bounds<H16>(P.bounds, bbase + i * 16) : bnd[i * 16 + r16]; };
 
     RowGains<NX, NU> G;
     G.load(P.mats, r16);
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(WAVE, 3) void admm_rowloop_kernel(const RowParams P
         {
             // ---------------- forward sweep: forward_pass + update_slack + update_dual + residual maxima ----------------
             float s = x0, pri = 0.f, dua = 0.f, t1 = 0.f;
-            float2 lh = bnd[r16];
+            float2 lh = bounds_at(0);
             float b_cur = b[0];
             int o = rowbase;
             // slack, dual and residual part of step i (sv = [x_i ; u_i]); reloads lh / b_cur for the next step AFTER their
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(WAVE, 3) void admm_rowloop_kernel(const RowParams P
                 b[i * WAVE] = t;
                 stw<H16>(P.vz, o, b_cur); // v_i | z_i, should this iteration converge
                 t1 = t - an;
-                lh = bnd[inext * 16 + r16];
+                lh = bounds_at(inext);
                 b_cur = b[inext * WAVE];
                 o += 16;
             };
@@ -244,8 +250,14 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowloop64_kernel(const RowParams
 
     float2 *bnd = reinterpret_cast<float2 *>(lds); // [N][16] {lo, hi}, shared by the batch
     float *b = lds + N * 32 + lane;                 // b[i * WAVE]
-    for (int e = lane; e < N * 16; e += WAVE) bnd[e] = ld_bounds<H16>(P.bounds, e);
+    // batch-shared bounds are staged in LDS once; per-instance bounds (bounds_inst_stride != 0: a [B][N][16] table) are read
+    // from global memory one step ahead of their use
+    const bool bpi = P.bounds_inst_stride != 0;
+    const int bbase = inst_a * (int)P.bounds_inst_stride + r16;
+    if (!bpi)
+        for (int e = lane; e < N * 16; e += WAVE) bnd[e] = ld_bounds<H16>(P.bounds, e);
     __syncthreads();
+    auto bounds_at = [&](int i) { return bpi ? ld_bounds<H16>(P.bounds, bbase + i * 16) : bnd[i * 16 + r16]; };
 
     RowGains<NX, NU> G;
     G.load(P.mats, r16);
@@ -304,7 +316,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowloop64_kernel(const RowParams
         {
             // ---------------- forward sweep ----------------
             float s = x0, pri = 0.f, dua = 0.f, t1 = 0.f;
-            float2 lh = bnd[r16];
+            float2 lh = bounds_at(0);
             float b_cur = b[0];
             int o = rowbase;
             auto fwd_step = [&](int i, float ai, float ci) {
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(WAVE, 2) void admm_rowloop64_kernel(const RowParams
                 stw<H16>(P.vz, o, b_cur); // v_i | z_i, should this iteration converge
                 t1 = t - an;
                 const int inext = i + 1 < N ? i + 1 : i;
-                lh = bnd[inext * 16 + r16];
+                lh = bounds_at(inext);
                 b_cur = b[inext * WAVE];
                 o += 16;
                 s = xn;

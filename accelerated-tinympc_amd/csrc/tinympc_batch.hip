@@ -746,10 +746,15 @@ int row_family(const TinyBatch *tb)
 {
     // one wavefront per instance: state on chip where the horizon fits (admm_waveres.hip, 6), else streamed through HBM (admm_wave.hip, 3)
     if (tb->wave_ok) return (tb->waveres_ok && tb->row_family_forced != 3) ? 6 : 3;
-    // per-instance bounds: the unrolled register-resident kernel reads them from the [B][N][16] table (fp32 storage), the
-    // streaming row kernel serves every other case; the rolled-loop and quad kernels stage one shared table in LDS
+    // per-instance bounds: the unrolled register-resident kernel (fp32 storage) and the rolled-loop ones (N <= 64, either storage)
+    // read them from the [B][N][16] table, the streaming row kernel serves every other case; the quad kernel stages one shared table
     if (!bounds_all_shared(tb))
-        return (tb->row_dims_ok && !tb->h16 && !tb->en_uref && !tb->en_d2p && (tb->row_family_forced < 0 || tb->row_family_forced == 0)) ? 0 : 2;
+    {
+        if (tb->en_uref || tb->en_d2p) return 2;
+        if (tb->row_dims_ok && !tb->h16 && (tb->row_family_forced < 0 || tb->row_family_forced == 0)) return 0;
+        if (tb->rowloop_ok && (tb->row_family_forced < 0 || tb->row_family_forced == 1)) return 1; // one step ahead from global memory
+        return 2;
+    }
     if (tb->en_uref || tb->en_d2p) return 2; // the optional terms live in the streaming row kernel (c's u rows hold d elsewhere)
     // 5 = sixteen instances per wave, products on the matrix cores (admm_tile16.hip): on request only; needs fp32 storage and
     // a reference it does not have to keep resident (window of a table, or one shared reference)

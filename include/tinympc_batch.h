@@ -178,7 +178,8 @@ extern "C"
      * 1 = streaming MFMA kernel (state in HBM, fma arithmetic), 2 = exact arithmetic (bitwise equal to the reference's
      * SSE2 build), 3 = fma arithmetic on the row kernels (nx + nu <= 16)
      * or on the state-on-chip wave kernel (16 < nx + nu <= 64, N <= 50).  Bounds may be batch-shared or per instance in
-     * every variant (per-instance bounds select the kernels that stream their state). */
+     * every variant (per-instance bounds stay on the register-resident 16-lane kernels for N <= 64; the quad kernel and longer
+     * horizons hand over to the kernels that stream their state). */
     int tiny_batch_select_kernel(TinyBatch *tb, int variant);
     /* Which row kernel variants 2/3 (and auto) launch: 0 = auto (4 where it exists, else 1 where (nx,nu,N) has an unrolled
      * instantiation, else 2 for N <= 64, else 3), 1 = rowlane (16 lanes per instance, unrolled, state in registers/LDS),

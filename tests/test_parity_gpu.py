@@ -253,10 +253,11 @@ def test_settings_variants_vs_oracle(tinympc, oracle_mod, variant):
         orc = O.Oracle(prob, np.float32, settings)
         sol = make_solver(tinympc, prob, B, settings, xref, variant, bnds)
         if bnds[0].ndim == 3 and variant != "stream":
-            # per-instance bounds: the unrolled register-resident kernel reads them per lane-step from the [B][N][16] table;
-            # the rolled-loop kernel stages ONE table in LDS, so a handle forced onto it runs on the streaming row kernel
-            # instead (same arithmetic either way: still bitwise when exact)
-            want = "rowlane" if VARIANTS[variant][2] in (0, 1) else "rowstream"
+            # per-instance bounds: the unrolled and the rolled-loop register-resident kernels read them per lane-step from the
+            # [B][N][16] table; a handle forced onto another family runs on the streaming row kernel (same arithmetic: still
+            # bitwise when exact)
+            fam = VARIANTS[variant][2]
+            want = "rowlane" if fam in (0, 1) else "rowloop" if fam == 2 else "rowstream"
             assert sol.kernel_name().startswith(want), (variant, sol.kernel_name())
         st = O.new_state(B, 12, 4, 30)
         st["x"][:, 0] = x0
@@ -1348,11 +1349,13 @@ def test_kernel_selection_and_option_errors(tinympc):
 
 def test_per_instance_bounds_exact(tinympc, oracle_mod):
     """Per-instance (and per-step) box bounds — every reference workspace owns its u_min .. x_max (types.hpp:88-91) — in exact
-    arithmetic: the quadrotor class stays on the register-resident row kernel (bounds read per lane-step from the [B][N][16]
-    table), fp16 storage and horizons without an unrolled instantiation run on the streaming row kernel, the nx = 32 class on
-    the wave kernel, and update_slack works as a separate call — all bitwise equal to the oracle."""
+    arithmetic: the quadrotor class stays on the register-resident row kernels (bounds read per lane-step from the [B][N][16]
+    table: unrolled for N = 30 in fp32 storage, rolled-loop for fp16 storage and for horizons without an unrolled instantiation
+    up to 64), longer horizons run on the streaming row kernel, the nx = 32 class on the wave kernel, and update_slack works as
+    a separate call — all bitwise equal to the oracle."""
     O, pr = oracle_mod, tinympc.problems
-    for prob, B, name in ((pr.quadrotor(20, 30), 37, "rowlane"), (pr.quadrotor(20, 17), 21, "rowstream"), (pr.random_system(32, 16, 50), 5, "waveres")):
+    for prob, B, name in ((pr.quadrotor(20, 30), 37, "rowlane"), (pr.quadrotor(20, 17), 21, "rowloop"), (pr.quadrotor(20, 47), 9, "rowloop"),
+                          (pr.quadrotor(20, 66), 6, "rowstream"), (pr.random_system(32, 16, 50), 5, "waveres")):
         nx, nu, N = prob["nx"], prob["nu"], prob["N"]
         rng = np.random.default_rng(B)
         x0 = rng.uniform(-0.4, 0.4, size=(B, nx)).astype(np.float32)
@@ -1363,7 +1366,7 @@ def test_per_instance_bounds_exact(tinympc, oracle_mod):
             sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
             sol.set_storage(storage)
             sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
-            want = "rowstream" if (storage == 16 and name == "rowlane") else name
+            want = "rowloop" if (storage == 16 and name == "rowlane") else name
             assert sol.kernel_name().startswith(want), sol.kernel_name()
             R = O.round_h16 if storage == 16 else (lambda a: a)
             orc = O.Oracle(prob, "h16" if storage == 16 else np.float32, settings)
