@@ -222,7 +222,7 @@ def test_native_names_header_is_plain_c_and_matches_the_binding(tinympc, tmp_pat
         assert [f[0] for f in native.TinyWorkspace._fields_[3:]] == ref_members
 
 
-@pytest.mark.parametrize("name", ["r01_bench_default_line.json", "r02_bench_default_line_c.json", "r02_bench_random32_line_b.json"])
+@pytest.mark.parametrize("name", ["r01_bench_default_line.json", "r02_bench_default_line_d.json", "r02_bench_random32_line_b.json"])
 def test_recorded_bench_line_has_the_contract_fields(name):
     """profiles/*_bench_*_line*.json are the stdout of `python bench.py [--config random32]` on the MI355X: the keys the driver reads."""
     import json
