@@ -70,6 +70,69 @@ __device__ __forceinline__ void gather4(float (&t)[4], const f32x16 &p)
     for (int b = 0; b < 4; b++) t[b] = p[4 * b + V];
 }
 
+// ---- packed sums (round 3).  An MFMA result holds, for gain column b, the products of output registers V = 0..3 in the four
+// CONSECUTIVE registers 4b .. 4b+3: a natural 4-vector.  Where the four rows of a lane are summed in the same order the sums
+// are written over such 4-vectors, and every 4-vector add is two v_pk_add_f32 (registers (0,1) and (2,3); each half is the IEEE
+// fp32 add of v_add_f32, separately rounded: the results stay bitwise those of the reference).  With ONE wave per SIMD — all
+// this kernel's register budget allows — a wave issues a vector instruction every 4 clocks whatever it is, so packed adds double
+// the add rate (tools/micro/pk_rate.hip, profiles/r03_pk_rate.txt).  The two halves of a 4-vector add are independent, which
+// also keeps a packed result one instruction away from its use: gfx950 needs one wait state there, and a lone dependent chain
+// of v_pk_add_f32 would pay it as an s_nop per add.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int B> // products of gain column B of an MFMA result, rows V = 0..3
+__device__ __forceinline__ f32x4 blk(const f32x16 &p) { return __builtin_shufflevector(p, p, 4 * B, 4 * B + 1, 4 * B + 2, 4 * B + 3); }
+__device__ __forceinline__ void gather12v(f32x4 (&t)[12], const f32x16 &p0, const f32x16 &p1, const f32x16 &p2)
+{
+    t[0] = blk<0>(p0); t[1] = blk<1>(p0); t[2] = blk<2>(p0); t[3] = blk<3>(p0);
+    t[4] = blk<0>(p1); t[5] = blk<1>(p1); t[6] = blk<2>(p1); t[7] = blk<3>(p1);
+    t[8] = blk<0>(p2); t[9] = blk<1>(p2); t[10] = blk<2>(p2); t[11] = blk<3>(p2);
+}
+__device__ __forceinline__ void gather4v(f32x4 (&t)[4], const f32x16 &p)
+{
+    t[0] = blk<0>(p); t[1] = blk<1>(p); t[2] = blk<2>(p); t[3] = blk<3>(p);
+}
+// the reduction plans of rowlane_math.h over 4-vectors of rows
+template <int LO, int CNT, int NN>
+__device__ __forceinline__ f32x4 tree_sum4(const f32x4 (&t)[NN])
+{
+    if constexpr (CNT == 1) return t[LO];
+    else
+    {
+        constexpr int H = CNT / 2;
+        return tree_sum4<LO, H>(t) + tree_sum4<LO + H, CNT - H>(t);
+    }
+}
+template <int PLO, int PCNT, int L, int NN>
+__device__ __forceinline__ f32x4 ptree_sum4(const f32x4 (&t)[NN])
+{
+    if constexpr (PCNT == 1) return t[4 * PLO + L];
+    else
+    {
+        constexpr int H = PCNT / 2;
+        return ptree_sum4<PLO, H, L>(t) + ptree_sum4<PLO + H, PCNT - H, L>(t);
+    }
+}
+template <int PLAN, int NN>
+__device__ __forceinline__ f32x4 reduce4(const f32x4 (&t)[NN])
+{
+    if constexpr (NN == 1) return t[0];
+    else if constexpr (PLAN == PLAN_SEQ)
+    {
+        f32x4 acc = t[0];
+#pragma unroll
+        for (int k = 1; k < NN; k++) acc = acc + t[k];
+        return acc;
+    }
+    else if constexpr (PLAN == PLAN_TREE) return tree_sum4<0, NN>(t);
+    else
+    {
+        static_assert(NN % 4 == 0, "packed VEC plan: whole packets only");
+        constexpr int NPK = NN / 4;
+        const f32x4 s0 = ptree_sum4<0, NPK, 0>(t), s1 = ptree_sum4<0, NPK, 1>(t), s2 = ptree_sum4<0, NPK, 2>(t), s3 = ptree_sum4<0, NPK, 3>(t);
+        return (s0 + s2) + (s1 + s3);
+    }
+}
+
 template <bool EXACT>
 struct TileMath
 {
@@ -100,17 +163,16 @@ struct TileMath
         if constexpr (EXACT)
         {
             const f32x16 p0 = TINY_MFMA1(A1[0], s[0], negz), p1 = TINY_MFMA1(A1[1], s[1], negz), p2 = TINY_MFMA1(A1[2], s[2], negz);
-            float t[12], acc[3];
-            gather12<0>(t, p0, p1, p2); acc[0] = reduce<PL::FWD_XA>(t);
-            gather12<1>(t, p0, p1, p2); acc[1] = reduce<PL::FWD_XA>(t);
-            gather12<2>(t, p0, p1, p2); acc[2] = reduce<PL::FWD_XA>(t);
-            gather12<3>(t, p0, p1, p2);
-            un = -reduce<PL::FWD_U>(t) - di; // -(K x) - d: the SUM is negated, as in the reference
+            static_assert(PL::FWD_XA == PL::FWD_U, "x rows and the u row of a lane are summed in one order (both SEQ for nx = 12, nu = 4)");
+            f32x4 t[12];
+            gather12v(t, p0, p1, p2);
+            const f32x4 acc = reduce4<PL::FWD_XA>(t); // [0..2]: A x of the x rows, [3]: K x of the u row
+            un = -acc[3] - di; // -(K x) - d: the SUM is negated, as in the reference
             const f32x16 pb = TINY_MFMA1(A2, un, negz);
-            float t2[4];
-            gather4<0>(t2, pb); xn[0] = acc[0] + reduce<PL::FWD_XB>(t2);
-            gather4<1>(t2, pb); xn[1] = acc[1] + reduce<PL::FWD_XB>(t2);
-            gather4<2>(t2, pb); xn[2] = acc[2] + reduce<PL::FWD_XB>(t2);
+            f32x4 t2[4];
+            gather4v(t2, pb);
+            const f32x4 xn4 = acc + reduce4<PL::FWD_XB>(t2); // register 3 carries no row here
+            xn[0] = xn4[0]; xn[1] = xn4[1]; xn[2] = xn4[2];
         }
         else
         {
@@ -125,22 +187,24 @@ struct TileMath
     }
 
     // backward_pass_grad step (admm.cpp:19-20): p = p_{i+1}, lin = [q_i ; r_i]  ->  pn = p_i, dd = d_i
-    __device__ __forceinline__ void riccati(const float (&p)[3], const float (&lin)[4], float (&pn)[3], float &dd) const
+    __device__ __forceinline__ void riccati(const float (&p)[3], const f32x4 &lin, float (&pn)[3], float &dd) const
     {
         if constexpr (EXACT)
         {
             const f32x16 p0 = TINY_MFMA1(A3[0], p[0], negz), p1 = TINY_MFMA1(A3[1], p[1], negz), p2 = TINY_MFMA1(A3[2], p[2], negz);
             const f32x16 pk = TINY_MFMA1(A45, lin[3], negz); // Kinf^T r (x rows)
-            float t[12], wv[4];
-            gather12<0>(t, p0, p1, p2); wv[0] = lin[0] + reduce<PL::BWD_PA>(t);
-            gather12<1>(t, p0, p1, p2); wv[1] = lin[1] + reduce<PL::BWD_PA>(t);
-            gather12<2>(t, p0, p1, p2); wv[2] = lin[2] + reduce<PL::BWD_PA>(t);
-            gather12<3>(t, p0, p1, p2); wv[3] = lin[3] + reduce<PL::BWD_TMP>(t); // Bdyn^T p + r
-            const f32x16 pq = TINY_MFMA1(A45, wv[3], negz); // Quu_inv (Bdyn^T p + r) (u row)
+            f32x4 t4[12];
+            gather12v(t4, p0, p1, p2);
+            const f32x4 wv = lin + reduce4<PL::BWD_PA>(t4); // the three x rows in one packed tree; register 3 is not used:
+            float t[12];                                    // the u row sums in its own order
+            gather12<3>(t, p0, p1, p2);
+            const float wv3 = lin[3] + reduce<PL::BWD_TMP>(t); // Bdyn^T p + r
+            const f32x16 pq = TINY_MFMA1(A45, wv3, negz);       // Quu_inv (Bdyn^T p + r) (u row)
+            f32x4 tk4[4];
+            gather4v(tk4, pk);
+            const f32x4 pn4 = wv - reduce4<PL::BWD_PK>(tk4);
+            pn[0] = pn4[0]; pn[1] = pn4[1]; pn[2] = pn4[2];
             float tk[4];
-            gather4<0>(tk, pk); pn[0] = wv[0] - reduce<PL::BWD_PK>(tk);
-            gather4<1>(tk, pk); pn[1] = wv[1] - reduce<PL::BWD_PK>(tk);
-            gather4<2>(tk, pk); pn[2] = wv[2] - reduce<PL::BWD_PK>(tk);
             gather4<3>(tk, pq); dd = reduce<PL::BWD_D>(tk);
         }
         else
@@ -202,13 +266,13 @@ __device__ __forceinline__ void acc_init(float &dst, float val) { asm volatile("
 // The state updates of one horizon step, applied to the lanes in `m` only (the instances still iterating).  Written as ONE
 // asm block that narrows EXEC itself: expressed as `if (active) { ... }` the 60 small regions per iteration make hipcc keep
 // the old and the new value of every state word alive side by side (twice the state: hundreds of spilled registers).
-typedef float f32x4v __attribute__((ext_vector_type(4)));
+// The new dual a = tp - t (admm.cpp:69-70, (y + u) - znew) is computed here, straight into its state registers.
 typedef __attribute__((address_space(3))) float4 lds_float4;
-__device__ __forceinline__ void masked_forward_update(unsigned long long m, float (&a)[4], const float (&an)[4], float (&bo)[4],
-                                                      const float (&old)[4], unsigned sn_addr, const float (&t)[4])
+__device__ __forceinline__ void masked_forward_update(unsigned long long m, float (&a)[4], const f32x4 &tp, float (&bo)[4], const f32x4 &old,
+                                                      unsigned sn_addr, const f32x4 &t)
 {
     unsigned long long sx;
-    const f32x4v tv = {t[0], t[1], t[2], t[3]};
+    const f32x4 an = tp - t;
     asm volatile("s_and_saveexec_b64 %[sx], %[m]\n\t"
                  "v_mov_b32 %[a0], %[n0]\n\tv_mov_b32 %[a1], %[n1]\n\tv_mov_b32 %[a2], %[n2]\n\tv_mov_b32 %[a3], %[n3]\n\t"
                  "v_accvgpr_write_b32 %[b0], %[o0]\n\tv_accvgpr_write_b32 %[b1], %[o1]\n\tv_accvgpr_write_b32 %[b2], %[o2]\n\tv_accvgpr_write_b32 %[b3], %[o3]\n\t"
@@ -217,32 +281,50 @@ __device__ __forceinline__ void masked_forward_update(unsigned long long m, floa
                  : [sx] "=&s"(sx), [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [b0] "+a"(bo[0]), [b1] "+a"(bo[1]),
                    [b2] "+a"(bo[2]), [b3] "+a"(bo[3])
                  : [m] "s"(m), [n0] "v"(an[0]), [n1] "v"(an[1]), [n2] "v"(an[2]), [n3] "v"(an[3]), [o0] "v"(old[0]), [o1] "v"(old[1]),
-                   [o2] "v"(old[2]), [o3] "v"(old[3]), [ad] "v"(sn_addr), [tv] "v"(tv)
+                   [o2] "v"(old[2]), [o3] "v"(old[3]), [ad] "v"(sn_addr), [tv] "v"(t)
                  : "memory", "scc"); // s_and_saveexec writes SCC
 }
-__device__ __forceinline__ void masked_backward_update(unsigned long long m, float (&pl)[3], float &dl, const float (&pn)[3], float dd)
+__device__ __forceinline__ void masked_backward_update(unsigned long long m, float (&pl)[3], float &dr, const float (&pn)[3], float dd)
 {
     unsigned long long sx;
     asm volatile("s_and_saveexec_b64 %[sx], %[m]\n\t"
-                 "v_accvgpr_write_b32 %[p0], %[n0]\n\tv_accvgpr_write_b32 %[p1], %[n1]\n\tv_accvgpr_write_b32 %[p2], %[n2]\n\tv_accvgpr_write_b32 %[d], %[dd]\n\t"
+                 "v_accvgpr_write_b32 %[p0], %[n0]\n\tv_accvgpr_write_b32 %[p1], %[n1]\n\tv_accvgpr_write_b32 %[p2], %[n2]\n\tv_mov_b32 %[d], %[dd]\n\t"
                  "s_mov_b64 exec, %[sx]"
-                 : [sx] "=&s"(sx), [p0] "+a"(pl[0]), [p1] "+a"(pl[1]), [p2] "+a"(pl[2]), [d] "+a"(dl)
+                 : [sx] "=&s"(sx), [p0] "+a"(pl[0]), [p1] "+a"(pl[1]), [p2] "+a"(pl[2]), [d] "+v"(dr)
                  : [m] "s"(m), [n0] "v"(pn[0]), [n1] "v"(pn[1]), [n2] "v"(pn[2]), [dd] "v"(dd)
                  : "scc");
+}
+
+// [q_i ; r_i] of update_linear_cost (admm.cpp:80-82) for the four rows of a lane: cq - rho * (snew - dual)
+template <bool EXACT>
+__device__ __forceinline__ f32x4 lin_cost4(const f32x4 &cq, const f32x4 &rho4, const f32x4 &t1)
+{
+    if constexpr (EXACT) return cq - rho4 * t1;
+    else return __builtin_elementwise_fma(-rho4, t1, cq);
 }
 
 constexpr int TILE16_WAVES = 4;         // waves per workgroup = one per SIMD of a CU; they share the bounds and reference tables
 constexpr int TILE16_MAX_TABLE_ROWS = 512;
 
-template <int N, bool EXACT>
+// COLD: the launch starts from reset_workspace() (RowParams::cold_start): no live-in array is read (round 3: a separate
+// instantiation — as a run-time branch the two initialisations meet in 270 phi values and the allocator spills)
+template <int N, bool EXACT, bool COLD>
 __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(const RowParams P)
 {
     constexpr int NX = 12, NU = 4;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-    const int inst = (blockIdx.x * TILE16_WAVES + wv) * 16 + c;
-    const bool valid = inst < P.batch;
+    // dispatch order (round 3): wave w of workgroup b solves tile order[4b + w]; workgroups start in index order, so a list
+    // sorted by the predicted iteration count starts the long tiles first AND puts tiles of similar length on one CU
+    const int ntiles = (P.batch + 15) >> 4;
+    const int slot = blockIdx.x * TILE16_WAVES + wv;
+    int tile = slot;
+    if (P.order) tile = slot < ntiles ? P.order[slot] : ntiles;
+    const bool tile_ok = tile >= 0 && tile < ntiles; // also rejects a bad entry of a caller-supplied order: such a wave stores nothing
+    const int inst = tile * 16 + c;
+    const bool valid = tile_ok && inst < P.batch;
     const int inst_a = valid ? inst : P.batch - 1; // padding columns of the last tile load a valid instance and store nothing
     const float rho = P.rho;
+    const f32x4 rho4 = {rho, rho, rho, rho};
 
     // ---- LDS (dynamic): per wave the slack [v|vnew ; z|znew] of every step (lane-linear float4), then the tables the four
     //      waves share: box bounds [step][g] -> registers v = 0..3 (row 4v + g), reference rows [row][g] -> x rows 4v + g
@@ -264,65 +346,89 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
 
     TileMath<EXACT> M;
     M.load(P.mats, g, c);
-    float qv[3];
+    // Q of the lane's x rows; register 3 is the u row, whose cost term is -(0 * 1) = -0 (the table's columns 12..15 are zero):
+    // r = -rho*(znew - y) keeps the sign of a zero difference
+    f32x4 qv;
 #pragma unroll
     for (int v = 0; v < 3; v++) qv[v] = P.mats[(2 * NX + 2 * NU) * 16 + 4 * v + g];
+    qv[3] = 1.f;
 
     // ---- per-instance state, four words per horizon step (row 4v + g) ----
-    //   a[i]   : g_i | y_i      duals                                                           (VGPR)
+    //   a[i]   : g_i | y_i      duals                                                           (VGPR; four SEPARATE registers: as
+    //            register pairs or quads the 120 words fragment the file and the allocator spills 250 registers)
     //   dr[i]  : d_i            feed-forward the forward sweep uses                              (VGPR)
     //   sn[i]  : before forward step i of an iteration the OLD slack v_i | z_i (what the previous iteration's sweep left, = v
     //            after admm.cpp:141-142), afterwards the new one vnew_i | znew_i                (LDS)
     //   bo[i]  : backup of the old slack this iteration's forward sweep replaced — the live-out v, z of an instance that
     //            converges in this iteration (the reference returns before v = vnew)            (AGPR, write-mostly)
-    //   pl[i], dl[i] : p_i, d_i of the last executed backward sweep, live-out only             (AGPR, write-only in the loop)
-    float a[N][4], dr[N], bo[N][4], pl[N][3], dl[N];
+    //   pl[i]  : p_i of the last backward sweep executed inside the iteration loop, live-out only (AGPR, write-only in the loop);
+    //            its d_i is dr[i].  The backward sweep of the LAST permitted iteration (an instance that exhausts max_iter) is
+    //            deferred to the epilogue: x, u of such an instance come from the d its last forward sweep used, which that
+    //            sweep must not overwrite — round 2 kept a second copy dl[] of d for this, 30 registers the allocator no
+    //            longer has since the sums are packed
+    float a[N][4];
+    float dr[N], bo[N][4], pl[N][3];
+    auto dual4 = [&](int i) { return f32x4{a[i][0], a[i][1], a[i][2], a[i][3]}; };
     const int ebase = (inst_a * N) * 16 + g; // element 4v + g of step i: ebase + i*16 + 4v
     int wstart = 0;
     if (P.xref_mode == 1) wstart = P.xref_start[inst_a];
-    const bool cold = P.cold_start != 0;
-    const bool zdual = cold || (P.duals_zero != 0);
+    const bool zdual = COLD || (P.duals_zero != 0);
 
-#pragma unroll
-    for (int i = 0; i < N; i++)
+    if constexpr (COLD) // reset_workspace() folded into the launch: nothing is read (round 3: the loads used to be issued and discarded)
     {
-        float vzl[4], pdv[4];
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int v = 0; v < 4; v++)
+        for (int i = 0; i < N; i++)
         {
-            const int o = ebase + i * 16 + 4 * v;
-            vzl[v] = P.vz[o]; pdv[v] = P.pd[o];
-            const float gyv = P.gy[o];
-            vzl[v] = cold ? 0.f : vzl[v];
-            pdv[v] = cold ? 0.f : pdv[v];
-            a[i][v] = zdual ? 0.f : gyv;
-            acc_init(bo[i][v], vzl[v]);
+            a[i][0] = a[i][1] = a[i][2] = a[i][3] = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc_init(bo[i][v], 0.f);
+            sn[i * WAVE] = z4;
+            acc_init(pl[i][0], 0.f); acc_init(pl[i][1], 0.f); acc_init(pl[i][2], 0.f);
+            dr[i] = 0.f;
         }
-        sn[i * WAVE] = make_float4(vzl[0], vzl[1], vzl[2], vzl[3]);
-        acc_init(pl[i][0], pdv[0]); acc_init(pl[i][1], pdv[1]); acc_init(pl[i][2], pdv[2]); acc_init(dl[i], pdv[3]);
-        dr[i] = pdv[3];
+    }
+    else
+    {
+#pragma unroll
+        for (int i = 0; i < N; i++)
+        {
+            float vzl[4], pdv[4];
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+            {
+                const int o = ebase + i * 16 + 4 * v;
+                vzl[v] = P.vz[o]; pdv[v] = P.pd[o];
+                const float gyv = P.gy[o];
+                a[i][v] = zdual ? 0.f : gyv;
+                acc_init(bo[i][v], vzl[v]);
+            }
+            sn[i * WAVE] = make_float4(vzl[0], vzl[1], vzl[2], vzl[3]);
+            acc_init(pl[i][0], pdv[0]); acc_init(pl[i][1], pdv[1]); acc_init(pl[i][2], pdv[2]);
+            dr[i] = pdv[3];
+        }
     }
     float x0[3];
 #pragma unroll
     for (int v = 0; v < 3; v++) x0[v] = P.xu[ebase + 4 * v];
 
-    // x rows of Xref_i for this lane (registers 0..2)
-    auto load_xref = [&](const float4 *tb, int ws, int i, float(&xr)[3]) {
+    // Xref_i for this lane: x rows in registers 0..2, register 3 = 0 (column 12 + g of the 16-wide table row)
+    auto load_xref = [&](const float4 *tb, int ws, int i) {
         int row = ws + i;
         row = row < tab_rows ? row : tab_rows - 1;
         const float4 t4 = tb[row * 4 + g];
-        xr[0] = t4.x; xr[1] = t4.y; xr[2] = t4.z;
+        return f32x4{t4.x, t4.y, t4.z, t4.w};
     };
     float pterm[3];
     {
-        float xrN[3];
-        load_xref(tab, wstart, N - 1, xrN);
+        const f32x4 xrN4 = load_xref(tab, wstart, N - 1);
+        const float xrN[3] = {xrN4[0], xrN4[1], xrN4[2]};
         M.terminal(xrN, pterm);
     }
 
     int st = TINY_STATUS_UNSOLVED_, itn = 1; // admm.cpp:114-115
     float r_ps = 0.f, r_pi = 0.f, r_ds = 0.f, r_di = 0.f;
-    if (valid && !P.cold_start)
+    if (valid && !COLD)
     {
         r_ps = P.res[4 * inst + 0]; r_pi = P.res[4 * inst + 1];
         r_ds = P.res[4 * inst + 2]; r_di = P.res[4 * inst + 3];
@@ -333,9 +439,6 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
     for (int it = 0; it < P.max_iter; ++it)
     {
         if (!__any(active)) break;
-        // the last permitted iteration must not overwrite d in dr[]: x,u of an instance that exhausts max_iter come from the
-        // d its last forward sweep used (regenerated in the epilogue); the final d itself goes to dl[] only
-        const bool keep_d = (it == P.max_iter - 1);
         // An opaque zero, re-made in every iteration, enters every LDS address of the sweeps: the addresses (30 slack slots, 30
         // bounds rows, 30 clamped reference rows per lane) are loop invariant, and hipcc would otherwise compute them all
         // ahead of the iteration loop and hold — in fact spill — them
@@ -354,30 +457,25 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
 #pragma unroll
         for (int i = 0; i < N; i++)
         {
-            float sv[4], xn[3] = {0.f, 0.f, 0.f};
-            sv[0] = s[0]; sv[1] = s[1]; sv[2] = s[2]; sv[3] = 0.f;
-            if (i < N - 1) M.lqr(s, dr[i], sv[3], xn);
+            float un = 0.f, xn[3] = {0.f, 0.f, 0.f};
+            if (i < N - 1) M.lqr(s, dr[i], un, xn);
+            const f32x4 sv = {s[0], s[1], s[2], un};
             const float4 lo = bloI[i * 4 + g], hi = bhiI[i * 4 + g], ol = snI[i * WAVE];
-            const float lov[4] = {lo.x, lo.y, lo.z, lo.w}, hiv[4] = {hi.x, hi.y, hi.z, hi.w}, old[4] = {ol.x, ol.y, ol.z, ol.w};
-            float t[4], an[4];
-#if TINY_T16_ABLATE == 2 // timing experiment: no slack / dual / residual arithmetic (results are wrong)
-#pragma unroll
-            for (int v = 0; v < 4; v++) { t[v] = sv[v]; an[v] = a[i][v]; }
-#else
-#pragma unroll
-            for (int v = 0; v < 4; v++)
-            {
-                const float tp = sv[v] + a[i][v];                         // admm.cpp:47-48
-                t[v] = __builtin_amdgcn_fmed3f(tp, lov[v], hiv[v]);       // :51-60 (lo := min(lo, hi) on the host)
-                an[v] = tp - t[v];                                        // :69-70  (y + u) - znew
-                const float dp = fabsf(sv[v] - t[v]), dd_ = fabsf(old[v] - t[v]); // :95-98
-                if (v < 3) { pri_x = fmaxf(pri_x, dp); dua_x = fmaxf(dua_x, dd_); }
-                else { pri_u = fmaxf(pri_u, dp); dua_u = fmaxf(dua_u, dd_); }
-            }
-#endif
-            masked_forward_update(amask, a[i], an, bo[i], old, sn_addr + i * (WAVE * 16), t);
+            const f32x4 old = {ol.x, ol.y, ol.z, ol.w};
+            const f32x4 tp = sv + dual4(i);                                        // admm.cpp:47-48
+            f32x4 t;
+            t[0] = __builtin_amdgcn_fmed3f(tp[0], lo.x, hi.x);                  // :51-60 (lo := min(lo, hi) on the host)
+            t[1] = __builtin_amdgcn_fmed3f(tp[1], lo.y, hi.y);
+            t[2] = __builtin_amdgcn_fmed3f(tp[2], lo.z, hi.z);
+            t[3] = __builtin_amdgcn_fmed3f(tp[3], lo.w, hi.w);
+            const f32x4 dp = sv - t, dd_ = old - t;                             // :95-98
+            pri_x = fmaxf(fmaxf(fmaxf(pri_x, fabsf(dp[0])), fabsf(dp[1])), fabsf(dp[2]));
+            dua_x = fmaxf(fmaxf(fmaxf(dua_x, fabsf(dd_[0])), fabsf(dd_[1])), fabsf(dd_[2]));
+            pri_u = fmaxf(pri_u, fabsf(dp[3]));
+            dua_u = fmaxf(dua_u, fabsf(dd_[3]));
             if (i == N - 1)
             {
+                const f32x4 an = tp - t; // what masked_forward_update stores below
 #pragma unroll
                 for (int v = 0; v < 3; v++)
                 {
@@ -385,6 +483,7 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
                     pN[v] = active ? pn_ : pN[v];
                 }
             }
+            masked_forward_update(amask, a[i], tp, bo[i], old, sn_addr + i * (WAVE * 16), t); // a = tp - t (:69-70), slack, backup
             s[0] = xn[0]; s[1] = xn[1]; s[2] = xn[2];
         }
         // ---------------- termination_condition (admm.cpp:91-109) ----------------
@@ -403,25 +502,21 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
         }
         active = active && !conv;
         if (!__any(active)) break;
+        if (it == P.max_iter - 1) break; // the backward sweep of the last permitted iteration runs in the epilogue
         // ---------------- backward sweep: (v = vnew, z = znew are implicit: sn holds both) linear cost, backward_pass_grad ----------------
         {
             float p[3] = {pN[0], pN[1], pN[2]};
             const unsigned long long amask = __ballot(active);
-            const bool upd_d = active && !keep_d;
 #pragma unroll
             for (int i = N - 2; i >= 0; i--)
             {
                 const float4 sl = snI[i * WAVE];
-                const float sni[4] = {sl.x, sl.y, sl.z, sl.w};
-                float xr[3], lin[4];
-                load_xref(tabI, wsI, i, xr);
-#pragma unroll
-                for (int v = 0; v < 3; v++) lin[v] = lin_cost<EXACT>(-(xr[v] * qv[v]), rho, sni[v] - a[i][v]); // admm.cpp:81-82
-                lin[3] = lin_cost<EXACT>(-0.f, rho, sni[3] - a[i][3]);                                         // :80
+                const f32x4 sni = {sl.x, sl.y, sl.z, sl.w};
+                const f32x4 xr = load_xref(tabI, wsI, i);
+                const f32x4 lin = lin_cost4<EXACT>(-(xr * qv), rho4, sni - dual4(i)); // admm.cpp:80-82
                 float pn[3], dd;
                 M.riccati(p, lin, pn, dd);
-                dr[i] = upd_d ? dd : dr[i];
-                masked_backward_update(amask, pl[i], dl[i], pn, dd);
+                masked_backward_update(amask, pl[i], dr[i], pn, dd);
                 p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
             }
         }
@@ -439,42 +534,88 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
     }
 
     // ---------------- live-out: every work array written once ----------------
+    // Round 3: a lane holds elements {4v + g} of its instance's 64-byte step row, so stored as they stand the four registers go
+    // out as four dword stores that each cover 16 x 16 scattered bytes.  Instead every 4-vector passes through the step's own
+    // slack slot in LDS (free once it has been read; LDS operations of a wave execute in order): written lane-linear, read back
+    // transposed, so that lane l holds elements 4(l & 3) .. +3 of instance l >> 2 and ONE dwordx4 store per array and step puts
+    // out sixteen whole 64-byte rows, four adjacent lanes each.
     {
         const bool solved = st == TINY_STATUS_SOLVED_;
+        const int c2 = lane >> 2, q2 = lane & 3;
+        const int inst2 = tile * 16 + c2;
+        const bool valid2 = tile_ok && inst2 < P.batch;
+        const int obase2 = ((valid2 ? inst2 : 0) * N) * 16 + 4 * q2;
+        // (may_alias: the same LDS words are accessed as float4 slack, as 4-vectors and as single floats, in program order)
+        typedef float float_ma __attribute__((may_alias));
+        typedef f32x4 f32x4_ma __attribute__((may_alias));
+        float_ma *const stage_w = reinterpret_cast<float_ma *>(lds4 + wv * (N * WAVE));     // wave's slack area, as floats
+        const int rd_off = (c2 * 4 + q2);                                                    // + 64 * r floats, r = 0..3
+        auto put = [&](float *dst, int i, const f32x4 &val) {
+            float_ma *slot = stage_w + i * (WAVE * 4);
+            reinterpret_cast<f32x4_ma *>(slot)[lane] = val;                                  // lane (g, c): elements 4v + g at [lane][v]
+            asm volatile("" ::: "memory"); // the reads below fetch what OTHER lanes just wrote: nothing may move across (hipcc
+            f32x4 o;                       // otherwise sinks them under the store's predicate, past the next array's write)
+            o[0] = slot[rd_off]; o[1] = slot[rd_off + 64]; o[2] = slot[rd_off + 128]; o[3] = slot[rd_off + 192]; // element 4 q2 + r of instance c2
+            asm volatile("" ::: "memory");
+            if (valid2) *reinterpret_cast<f32x4 *>(dst + obase2 + i * 16) = o;
+        };
         float s[3] = {x0[0], x0[1], x0[2]};
 #pragma unroll
         for (int i = 0; i < N; i++)
         {
             // x,u: regenerated from the d of the last executed forward sweep by the same instruction sequence
-            float sv[4], xn[3] = {0.f, 0.f, 0.f};
-            sv[0] = s[0]; sv[1] = s[1]; sv[2] = s[2]; sv[3] = 0.f;
-            if (i < N - 1) M.lqr(s, dr[i], sv[3], xn);
-            const float4 sl = sn[i * WAVE];
-            const float sni[4] = {sl.x, sl.y, sl.z, sl.w};
-            float xr[3], lin[4];
-            load_xref(tab, wstart, i, xr);
+            float un = 0.f, xn[3] = {0.f, 0.f, 0.f};
+            if (i < N - 1) M.lqr(s, dr[i], un, xn);
+            const f32x4 sv = {s[0], s[1], s[2], un};
+            const f32x4 sni = reinterpret_cast<const f32x4_ma *>(stage_w + i * (WAVE * 4))[lane];
+            const f32x4 xr = load_xref(tab, wstart, i);
+            f32x4 lin = lin_cost4<EXACT>(-(xr * qv), rho4, sni - dual4(i));
+            if (i == N - 1) lin[3] = 0.f;
+            // p.col(N-1) is rewritten by every forward sweep (admm.cpp:83-84); the other columns and d come from the
+            // last backward sweep this instance executed (an instance that never ran one keeps its live-in p, d)
+            f32x4 pdv = {acc_get(pl[i][0]), acc_get(pl[i][1]), acc_get(pl[i][2]), dr[i]};
+            if (i == N - 1) pdv = f32x4{pN[0], pN[1], pN[2], 0.f};
+            // a converged instance returned before v = vnew (admm.cpp:135-142): its v, z are the slack the last sweep replaced
+            f32x4 vzv;
 #pragma unroll
-            for (int v = 0; v < 3; v++) lin[v] = lin_cost<EXACT>(-(xr[v] * qv[v]), rho, sni[v] - a[i][v]);
-            lin[3] = (i < N - 1) ? lin_cost<EXACT>(-0.f, rho, sni[3] - a[i][3]) : 0.f;
-            const float pdv[4] = {acc_get(pl[i][0]), acc_get(pl[i][1]), acc_get(pl[i][2]), acc_get(dl[i])};
-            if (valid)
+            for (int v = 0; v < 4; v++)
             {
-#pragma unroll
-                for (int v = 0; v < 4; v++)
-                {
-                    const int o = ebase + i * 16 + 4 * v;
-                    P.xu[o] = sv[v];
-                    P.qr[o] = lin[v];
-                    // p.col(N-1) is rewritten by every forward sweep (admm.cpp:83-84); the other columns and d come from the
-                    // last backward sweep this instance executed (an instance that never ran one keeps its live-in p, d)
-                    P.pd[o] = (i == N - 1) ? (v < 3 ? pN[v] : 0.f) : pdv[v];
-                    // a converged instance returned before v = vnew (admm.cpp:135-142): its v, z are the slack the last sweep replaced
-                    P.vz[o] = solved ? acc_get(bo[i][v]) : sni[v];
-                    P.vzn[o] = sni[v];
-                    P.gy[o] = a[i][v];
-                }
+                const float bov = acc_get(bo[i][v]);
+                vzv[v] = solved ? bov : sni[v];
             }
+            put(P.xu, i, sv);
+            put(P.qr, i, lin);
+            put(P.pd, i, pdv);
+            put(P.vz, i, vzv);
+            put(P.vzn, i, sni);
+            put(P.gy, i, dual4(i));
+            reinterpret_cast<f32x4_ma *>(stage_w + i * (WAVE * 4))[lane] = sni; // the slot gets its slack back: the deferred sweep below reads it
             s[0] = xn[0]; s[1] = xn[1]; s[2] = xn[2];
+        }
+        // The deferred backward sweep of the last permitted iteration (admm.cpp:141-144 with iter = max_iter): instances that
+        // exhausted max_iter get p, d from it; the others keep what pass 1 stored (the same lanes store again, in program order).
+        const unsigned long long umask = __ballot(valid && !solved);
+        if (umask != 0ull)
+        {
+            const bool unsolved2 = valid2 && ((umask >> c2) & 1ull); // storing lane l serves instance l >> 2 (g = 0 holds its flag at bit c)
+            float p[3] = {pN[0], pN[1], pN[2]};
+#pragma unroll
+            for (int i = N - 2; i >= 0; i--)
+            {
+                const f32x4 sni = reinterpret_cast<const f32x4_ma *>(stage_w + i * (WAVE * 4))[lane];
+                const f32x4 xr = load_xref(tab, wstart, i);
+                const f32x4 lin = lin_cost4<EXACT>(-(xr * qv), rho4, sni - dual4(i));
+                float pn[3], dd;
+                M.riccati(p, lin, pn, dd);
+                float_ma *slot = stage_w + i * (WAVE * 4);
+                reinterpret_cast<f32x4_ma *>(slot)[lane] = f32x4{pn[0], pn[1], pn[2], dd};
+                asm volatile("" ::: "memory");
+                f32x4 o;
+                o[0] = slot[rd_off]; o[1] = slot[rd_off + 64]; o[2] = slot[rd_off + 128]; o[3] = slot[rd_off + 192];
+                asm volatile("" ::: "memory");
+                if (unsolved2) *reinterpret_cast<f32x4 *>(P.pd + obase2 + i * 16) = o;
+                p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
+            }
         }
         if (valid && g == 0)
         {
@@ -508,9 +649,10 @@ hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t
     const size_t lds = (size_t)(TILE16_WAVES * N * WAVE + 2 * N * 4 + rows * 4) * sizeof(float4);
 #define TINY_TILE16_LAUNCH(NN, EX)                                                                                         \
     {                                                                                                                      \
-        hipError_t e = hipFuncSetAttribute((const void *)admm_tile16_kernel<NN, EX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        auto kern = P.cold_start ? admm_tile16_kernel<NN, EX, true> : admm_tile16_kernel<NN, EX, false>;                  \
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         if (e != hipSuccess) return e;                                                                                     \
-        hipLaunchKernelGGL((admm_tile16_kernel<NN, EX>), dim3(nblocks), dim3(WAVE * TILE16_WAVES), lds, stream, P);        \
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WAVE * TILE16_WAVES), lds, stream, P);                                \
         return hipGetLastError();                                                                                          \
     }
 #define TINY_TILE16_DISPATCH(NN)                  \

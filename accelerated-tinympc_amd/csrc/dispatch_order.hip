@@ -39,7 +39,7 @@ __global__ __launch_bounds__(WAVE) void dispatch_key_kernel(const RowParams P, f
         float sv, xn = 0.f;
         if (i < N - 1) lqr_step<NX, NU, false, H16>(G, is_x, is_u, s, cold ? 0.f : ldw<H16>(P.pd, o), sv, xn);
         else sv = is_x ? s : 0.f;
-        const float2 lh = ld_bounds<H16>(P.bounds, i * 16 + r16);
+        const float2 lh = ld_bounds<H16>(P.bounds, inst_a * (int)P.bounds_inst_stride + i * 16 + r16); // per-instance tables: this instance's own
         const float a = zdual ? 0.f : ldw<H16>(P.gy, o);
         pri = fmaxf(pri, fabsf(sv - __builtin_amdgcn_fmed3f(sv + a, lh.x, lh.y)));
         s = xn;
@@ -82,15 +82,34 @@ __global__ __launch_bounds__(1024) void dispatch_order_kernel(const float *__res
     for (int g = t; g < n; g += 1024) order[atomicAdd(&dst[bucket(key[g])], 1)] = g;
 }
 
-hipError_t launch_dispatch_order(int nx, int nu, bool h16, const RowParams &P, float *key, int *order, hipStream_t stream)
+// key of a tile of 16 instances (admm_tile16.hip) = the largest key of its four groups
+__global__ __launch_bounds__(256) void dispatch_tile_key_kernel(const float *__restrict__ key, float *__restrict__ tkey, int ngroups, int ntiles)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    float k = 0.f;
+    for (int j = 0; j < 4; j++)
+        if (4 * t + j < ngroups) k = fmaxf(k, key[4 * t + j]);
+    tkey[t] = k;
+}
+
+// tile != 0: order[] is a permutation of the ceil(batch/16) tiles of the 16-instances-per-wave kernel (key must have room for
+// ceil(batch/4) + ceil(batch/16) floats)
+hipError_t launch_dispatch_order(int nx, int nu, bool h16, const RowParams &P, float *key, int *order, hipStream_t stream, int tile)
 {
     const int ngroups = (P.batch + 3) / 4;
+    const int ntiles = (P.batch + 15) / 16;
 #define TINY_KEY_DISPATCH(NX, NU)                                                                                      \
     if (nx == NX && nu == NU)                                                                                          \
     {                                                                                                                  \
         if (h16) hipLaunchKernelGGL((dispatch_key_kernel<NX, NU, true>), dim3(ngroups), dim3(WAVE), 0, stream, P, key); \
         else hipLaunchKernelGGL((dispatch_key_kernel<NX, NU, false>), dim3(ngroups), dim3(WAVE), 0, stream, P, key);   \
-        hipLaunchKernelGGL(dispatch_order_kernel, dim3(1), dim3(1024), 0, stream, key, order, ngroups);                \
+        if (tile)                                                                                                      \
+        {                                                                                                              \
+            hipLaunchKernelGGL(dispatch_tile_key_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, stream, key, key + ngroups, ngroups, ntiles); \
+            hipLaunchKernelGGL(dispatch_order_kernel, dim3(1), dim3(1024), 0, stream, key + ngroups, order, ntiles);   \
+        }                                                                                                              \
+        else hipLaunchKernelGGL(dispatch_order_kernel, dim3(1), dim3(1024), 0, stream, key, order, ngroups);           \
         return hipGetLastError();                                                                                      \
     }
     TINY_FOR_EACH_ROWDIMS(TINY_KEY_DISPATCH)

@@ -869,7 +869,7 @@ int prepare_solve(TinyBatch *tb, int *variant)
     if (tb->gains_dirty) TRY(pack_gains(tb));
     if (tb->dispatch_mode == 1 && !tb->order_buf)
     {
-        TRY(dev_alloc_zero(&tb->key_buf, (size_t)tb->bpad4 / 4));
+        TRY(dev_alloc_zero(&tb->key_buf, (size_t)tb->bpad4 / 4 + (size_t)tb->bpad4 / 16 + 16)); // group keys, then tile keys
         TRY(dev_alloc_zero((float **)&tb->order_buf, (size_t)tb->bpad4 / 4));
     }
     {
@@ -897,13 +897,14 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
     HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, sizeof(int), tb->stream));
     // longest-first dispatch (dispatch_order.hip): predictor sweep + bucket sort ahead of the register-resident 16-lane kernels;
     // pays off only when the launch is several rounds of waves deep
-    const bool predicted_order = layout == LAYOUT_ROW && tb->dispatch_mode == 1 && !tb->order_dev && (row_family(tb) == 0 || row_family(tb) == 1) && !tb->dual32 &&
+    const int fam_l = layout == LAYOUT_ROW ? row_family(tb) : -1;
+    const bool predicted_order = layout == LAYOUT_ROW && tb->dispatch_mode == 1 && !tb->order_dev && (fam_l == 0 || fam_l == 1 || fam_l == 5) && !tb->dual32 &&
                                  tb->bpad4 / 4 >= kDispatchMinGroups && tb->max_iter > 1;
     if (predicted_order)
     {
         RowParams K;
         fill_row_params(tb, K, false); // fma gains
-        hipError_t ek = launch_dispatch_order(tb->nx, tb->nu, tb->h16, K, tb->key_buf, tb->order_buf, tb->stream);
+        hipError_t ek = launch_dispatch_order(tb->nx, tb->nu, tb->h16, K, tb->key_buf, tb->order_buf, tb->stream, fam_l == 5);
         if (ek != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(ek));
     }
     if (record_events) HIP_TRY(hipEventRecord(tb->ev0, tb->stream)); // the events bracket the solve kernel itself
@@ -938,6 +939,7 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
         fill_row_params(tb, P, v == VAR_ROW_EXACT);
         if (predicted_order) P.order = tb->order_buf;
         const int fam = row_family(tb);
+        if (fam == 5 && !predicted_order) P.order = nullptr; // a caller's order lists groups of four instances, not tiles of sixteen
         if (P.dual32 && fam != 0 && fam != 4)
             return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage with fp32 duals runs on the register-resident 16-lane and quad kernels only "
                                                  "(batch-shared bounds, no optional terms, no forced row kernel)");

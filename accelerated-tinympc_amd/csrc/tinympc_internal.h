@@ -101,6 +101,7 @@ struct RowParams
     unsigned uref_inst_stride;   // floats between instances (0 = shared)
     int en_d2p;                  // p_i += coeff_d2p * d_i
     const int *order;            // NULL, or a permutation of the ceil(batch/4) instance groups: workgroup b solves group order[b]
+                                 // (admm_tile16.hip: of the ceil(batch/16) tiles, wave w of workgroup b solves tile order[4b + w])
                                  // (register-resident 16-lane kernels only; results do not depend on it)
     float *res;
     int *status, *iter, *n_unsolved;
@@ -151,6 +152,6 @@ hipError_t launch_admm_stream(int nxc, int nuc, const SolveParams &P, hipStream_
 
 // longest-first dispatch order of the instance groups for the register-resident row kernel (dispatch_order.hip);
 // P.mats must be the fma gains
-hipError_t launch_dispatch_order(int nx, int nu, bool h16, const RowParams &P, float *key, int *order, hipStream_t stream);
+hipError_t launch_dispatch_order(int nx, int nu, bool h16, const RowParams &P, float *key, int *order, hipStream_t stream, int tile = 0);
 
 } // namespace tinympc
