@@ -23,10 +23,12 @@ HEADERS = [CSRC / "tinympc_internal.h", CSRC / "rowlane_math.h", CSRC / "tile_ma
 # -ffp-contract=off : exact arithmetic must not fuse a*b+c; the fast paths call fma explicitly
 # -fno-slp-vectorize: hipcc otherwise pairs scalar fp32 adds into v_pk_add_f32 (+ v_mov to build the pairs), which on
 #                     gfx950 is slower than two plain v_add_f32 (measured, tools/micro/*.hip)
-# per-file extras.  admm_tile16.hip: MFMA results go to VGPRs (the sums that consume the exact products are VALU instructions,
+# per-file extras.  admm_tile16.hip: the max-ILP scheduling strategy (one wave per SIMD: nothing else hides a latency; measured
+# 1.88 -> 1.79 ms, the other kernels do not react to it); MFMA results go to VGPRs (the sums that consume the exact products are VALU instructions,
 # which cannot read the accumulator half of the register file: left to its heuristics hipcc parks the products there and
 # copies every one of them back, 110 v_accvgpr_read per horizon step)
-EXTRA_FLAGS = {"admm_tile16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA_FLAGS = {"admm_tile16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"] + os.environ.get("TINYMPC_T16_FLAGS", "").split(),
+               "admm_rowlane.hip": os.environ.get("TINYMPC_ROWLANE_FLAGS", "").split()}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-gpu-rdc"]
 
 

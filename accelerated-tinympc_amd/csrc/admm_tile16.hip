@@ -41,6 +41,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef TINY_T16_ABLATE
 #define TINY_T16_ABLATE 0
 #endif
+#ifndef TINY_T16_SCHED
+#define TINY_T16_SCHED 1 // the scheduling fences pay in exact arithmetic only (measured: exact 2.01 -> 1.88 ms, fma 1.02 -> 1.08)
+#endif
 
 #if TINY_T16_ABLATE == 1 // timing experiment: no matrix-core work (results are wrong)
 __device__ __forceinline__ f32x4 t16_fake4(float a, float b, f32x4 c) { c[0] += a; c[1] += b; c[2] += a; c[3] += b; return c; }
@@ -157,15 +160,36 @@ struct TileMath
         for (int e = 0; e < 16; e++) negz[e] = -0.f;
     }
 
+    // The matrix-core part of a step is issued separately from the sums that consume it (round 3): the sweeps put independent
+    // vector work of the neighbouring step between the two, in the 40 .. 100 clocks the products take to arrive.
+    struct InFlight
+    {
+        f32x16 p0, p1, p2, pk; // exact: products of the three state slices (and of Kinf^T r in the backward step)
+        f32x4 acc;             // fma: the running chain
+    };
+
     // forward_pass step (admm.cpp:31,35): s = x_i (registers 0..2), di = d_i (u row)  ->  un = u_i, xn = x_{i+1}
-    __device__ __forceinline__ void lqr(const float (&s)[3], float di, float &un, float (&xn)[3]) const
+    __device__ __forceinline__ void lqr_issue(const float (&s)[3], InFlight &F) const
     {
         if constexpr (EXACT)
         {
-            const f32x16 p0 = TINY_MFMA1(A1[0], s[0], negz), p1 = TINY_MFMA1(A1[1], s[1], negz), p2 = TINY_MFMA1(A1[2], s[2], negz);
+            F.p0 = TINY_MFMA1(A1[0], s[0], negz); F.p1 = TINY_MFMA1(A1[1], s[1], negz); F.p2 = TINY_MFMA1(A1[2], s[2], negz);
+        }
+        else
+        {
+            f32x4 acc = {-0.f, -0.f, -0.f, -0.f}; // fma(a, b, -0) = a*b: the chain starts with a plain product, like dpp_fma_dot
+            acc = TINY_MFMA4(A1[0], s[0], acc);
+            acc = TINY_MFMA4(A1[1], s[1], acc);
+            F.acc = TINY_MFMA4(A1[2], s[2], acc);
+        }
+    }
+    __device__ __forceinline__ void lqr_finish(const InFlight &F, float di, float &un, float (&xn)[3]) const
+    {
+        if constexpr (EXACT)
+        {
             static_assert(PL::FWD_XA == PL::FWD_U, "x rows and the u row of a lane are summed in one order (both SEQ for nx = 12, nu = 4)");
             f32x4 t[12];
-            gather12v(t, p0, p1, p2);
+            gather12v(t, F.p0, F.p1, F.p2);
             const f32x4 acc = reduce4<PL::FWD_XA>(t); // [0..2]: A x of the x rows, [3]: K x of the u row
             un = -acc[3] - di; // -(K x) - d: the SUM is negated, as in the reference
             const f32x16 pb = TINY_MFMA1(A2, un, negz);
@@ -176,32 +200,47 @@ struct TileMath
         }
         else
         {
-            f32x4 acc = {-0.f, -0.f, -0.f, -0.f}; // fma(a, b, -0) = a*b: the chain starts with a plain product, like dpp_fma_dot
-            acc = TINY_MFMA4(A1[0], s[0], acc);
-            acc = TINY_MFMA4(A1[1], s[1], acc);
-            acc = TINY_MFMA4(A1[2], s[2], acc);
-            un = acc[3] - di; // u rows of M1 hold -Kinf in the fma table
-            acc = TINY_MFMA4(A2, un, acc);
+            un = F.acc[3] - di; // u rows of M1 hold -Kinf in the fma table
+            const f32x4 acc = TINY_MFMA4(A2, un, F.acc);
             xn[0] = acc[0]; xn[1] = acc[1]; xn[2] = acc[2];
         }
     }
+    __device__ __forceinline__ void lqr(const float (&s)[3], float di, float &un, float (&xn)[3]) const
+    {
+        InFlight F;
+        lqr_issue(s, F);
+        lqr_finish(F, di, un, xn);
+    }
 
     // backward_pass_grad step (admm.cpp:19-20): p = p_{i+1}, lin = [q_i ; r_i]  ->  pn = p_i, dd = d_i
-    __device__ __forceinline__ void riccati(const float (&p)[3], const f32x4 &lin, float (&pn)[3], float &dd) const
+    __device__ __forceinline__ void riccati_issue(const float (&p)[3], const f32x4 &lin, InFlight &F) const
     {
         if constexpr (EXACT)
         {
-            const f32x16 p0 = TINY_MFMA1(A3[0], p[0], negz), p1 = TINY_MFMA1(A3[1], p[1], negz), p2 = TINY_MFMA1(A3[2], p[2], negz);
-            const f32x16 pk = TINY_MFMA1(A45, lin[3], negz); // Kinf^T r (x rows)
+            F.p0 = TINY_MFMA1(A3[0], p[0], negz); F.p1 = TINY_MFMA1(A3[1], p[1], negz); F.p2 = TINY_MFMA1(A3[2], p[2], negz);
+            F.pk = TINY_MFMA1(A45, lin[3], negz); // Kinf^T r (x rows)
+        }
+        else
+        {
+            f32x4 acc = lin;
+            acc = TINY_MFMA4(A3[0], p[0], acc);
+            acc = TINY_MFMA4(A3[1], p[1], acc);
+            F.acc = TINY_MFMA4(A3[2], p[2], acc);
+        }
+    }
+    __device__ __forceinline__ void riccati_finish(const InFlight &F, const f32x4 &lin, float (&pn)[3], float &dd) const
+    {
+        if constexpr (EXACT)
+        {
             f32x4 t4[12];
-            gather12v(t4, p0, p1, p2);
+            gather12v(t4, F.p0, F.p1, F.p2);
             const f32x4 wv = lin + reduce4<PL::BWD_PA>(t4); // the three x rows in one packed tree; register 3 is not used:
             float t[12];                                    // the u row sums in its own order
-            gather12<3>(t, p0, p1, p2);
+            gather12<3>(t, F.p0, F.p1, F.p2);
             const float wv3 = lin[3] + reduce<PL::BWD_TMP>(t); // Bdyn^T p + r
             const f32x16 pq = TINY_MFMA1(A45, wv3, negz);       // Quu_inv (Bdyn^T p + r) (u row)
             f32x4 tk4[4];
-            gather4v(tk4, pk);
+            gather4v(tk4, F.pk);
             const f32x4 pn4 = wv - reduce4<PL::BWD_PK>(tk4);
             pn[0] = pn4[0]; pn[1] = pn4[1]; pn[2] = pn4[2];
             float tk[4];
@@ -209,16 +248,18 @@ struct TileMath
         }
         else
         {
-            f32x4 acc = {lin[0], lin[1], lin[2], lin[3]};
-            acc = TINY_MFMA4(A3[0], p[0], acc);
-            acc = TINY_MFMA4(A3[1], p[1], acc);
-            acc = TINY_MFMA4(A3[2], p[2], acc);
             const f32x4 nz = {-0.f, -0.f, -0.f, -0.f};
-            const f32x4 dq = TINY_MFMA4(A45, acc[3], nz); // u row: Quu_inv
-            acc = TINY_MFMA4(A45, lin[3], acc);           // x rows: -Kinf^T
+            const f32x4 dq = TINY_MFMA4(A45, F.acc[3], nz); // u row: Quu_inv
+            const f32x4 acc = TINY_MFMA4(A45, lin[3], F.acc); // x rows: -Kinf^T
             pn[0] = acc[0]; pn[1] = acc[1]; pn[2] = acc[2];
             dd = dq[3];
         }
+    }
+    __device__ __forceinline__ void riccati(const float (&p)[3], const f32x4 &lin, float (&pn)[3], float &dd) const
+    {
+        InFlight F;
+        riccati_issue(p, lin, F);
+        riccati_finish(F, lin, pn, dd);
     }
 
     // -(Xref_{N-1}^T Pinf) (admm.cpp:83), x rows
@@ -452,15 +493,11 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
         // The arithmetic of a sweep runs for all 16 columns (the MFMAs are wave-wide); only the state updates of a
         // converged instance are masked, which freezes it exactly where the reference returns.
         // ---------------- forward sweep: forward_pass + update_slack + update_dual + residual maxima ----------------
+        // Software pipelined by one step (round 3): step i issues its LDS reads (bounds, old slack) and its three product MFMAs,
+        // then runs the slack / dual / residual arithmetic of step i - 1 while those are in flight, then sums the products.
         float s[3] = {x0[0], x0[1], x0[2]};
         float pri_x = 0.f, dua_x = 0.f, pri_u = 0.f, dua_u = 0.f;
-#pragma unroll
-        for (int i = 0; i < N; i++)
-        {
-            float un = 0.f, xn[3] = {0.f, 0.f, 0.f};
-            if (i < N - 1) M.lqr(s, dr[i], un, xn);
-            const f32x4 sv = {s[0], s[1], s[2], un};
-            const float4 lo = bloI[i * 4 + g], hi = bhiI[i * 4 + g], ol = snI[i * WAVE];
+        auto elementwise = [&](int i, const f32x4 &sv, const float4 &lo, const float4 &hi, const float4 &ol) {
             const f32x4 old = {ol.x, ol.y, ol.z, ol.w};
             const f32x4 tp = sv + dual4(i);                                        // admm.cpp:47-48
             f32x4 t;
@@ -484,8 +521,26 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
                 }
             }
             masked_forward_update(amask, a[i], tp, bo[i], old, sn_addr + i * (WAVE * 16), t); // a = tp - t (:69-70), slack, backup
+        };
+        f32x4 sv_p = {0.f, 0.f, 0.f, 0.f};
+        float4 lo_p = make_float4(0.f, 0.f, 0.f, 0.f), hi_p = lo_p, ol_p = lo_p;
+#pragma unroll
+        for (int i = 0; i < N; i++)
+        {
+            const float4 lo = bloI[i * 4 + g], hi = bhiI[i * 4 + g], ol = snI[i * WAVE];
+            typename TileMath<EXACT>::InFlight F;
+            if (i < N - 1) M.lqr_issue(s, F);
+#if TINY_T16_SCHED
+            if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (i > 0) elementwise(i - 1, sv_p, lo_p, hi_p, ol_p);
+            float un = 0.f, xn[3] = {0.f, 0.f, 0.f};
+            if (i < N - 1) M.lqr_finish(F, dr[i], un, xn);
+            sv_p = f32x4{s[0], s[1], s[2], un};
+            lo_p = lo; hi_p = hi; ol_p = ol;
             s[0] = xn[0]; s[1] = xn[1]; s[2] = xn[2];
         }
+        elementwise(N - 1, sv_p, lo_p, hi_p, ol_p);
         // ---------------- termination_condition (admm.cpp:91-109) ----------------
         pri_x = tile_inst_max(pri_x); dua_x = tile_inst_max(dua_x);
         pri_u = tile_inst_max(pri_u); dua_u = tile_inst_max(dua_u);
@@ -507,17 +562,30 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
         {
             float p[3] = {pN[0], pN[1], pN[2]};
             const unsigned long long amask = __ballot(active);
-#pragma unroll
-            for (int i = N - 2; i >= 0; i--)
-            {
+            // the linear cost of step i - 1 depends on the state only, not on p: it is computed while the products of step i
+            // are in flight
+            auto make_lin = [&](int i) {
                 const float4 sl = snI[i * WAVE];
                 const f32x4 sni = {sl.x, sl.y, sl.z, sl.w};
                 const f32x4 xr = load_xref(tabI, wsI, i);
-                const f32x4 lin = lin_cost4<EXACT>(-(xr * qv), rho4, sni - dual4(i)); // admm.cpp:80-82
+                return lin_cost4<EXACT>(-(xr * qv), rho4, sni - dual4(i)); // admm.cpp:80-82
+            };
+            f32x4 lin = make_lin(N - 2);
+#pragma unroll
+            for (int i = N - 2; i >= 0; i--)
+            {
+                typename TileMath<EXACT>::InFlight F;
+                M.riccati_issue(p, lin, F);
+#if TINY_T16_SCHED
+                if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
+#endif
+                f32x4 lin_n = lin;
+                if (i > 0) lin_n = make_lin(i - 1);
                 float pn[3], dd;
-                M.riccati(p, lin, pn, dd);
+                M.riccati_finish(F, lin, pn, dd);
                 masked_backward_update(amask, pl[i], dr[i], pn, dd);
                 p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
+                lin = lin_n;
             }
         }
     }

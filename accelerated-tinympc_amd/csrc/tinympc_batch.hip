@@ -285,6 +285,8 @@ struct TinyBatch
     bool x0_zero_pending = false; // reset_workspace(): x.col(0) and x0buf read as zero until a set_x0 overwrites them
     int variant = VAR_AUTO;
     int row_family_forced = -1; // tiny_batch_set_row_kernel
+    int last_dispatch = 0;        // what the most recent solve launch did: 0 index order, 1 predicted longest first, 2 the caller's order
+    bool closed_loop_run = false; // inside tiny_batch_mpc_run_*(steps > 1): the auto choice keeps the kernel with the on-chip loop
     bool h16 = false; // ROW-layout arrays, Xref and bounds stored as IEEE binary16 (tiny_batch_set_storage)
     bool dual32 = false; // with h16: the duals pair gy stays fp32 (tiny_batch_set_storage_ex)
     bool timing = false;
@@ -713,6 +715,7 @@ int prepare_inputs(TinyBatch *tb, int layout)
 }
 
 int row_family(const TinyBatch *tb);
+constexpr int kTile16AutoBatch = 32768;
 
 int resolve_variant(TinyBatch *tb, int *out)
 {
@@ -742,6 +745,15 @@ int resolve_variant(TinyBatch *tb, int *out)
 // which of the three row kernels a row variant launches: 0 = unrolled register-resident (rowlane, fastest, one
 // instantiation per (nx, nu, N)), 1 = rolled-loop register-resident (rowloop, any N <= 64), 2 = any N with the state in
 // HBM (rowstream).  tiny_batch_set_row_kernel() can force one of them.
+// admm_tile16.hip needs fp32 storage, a reference it does not have to keep resident (a window of a trajectory table that
+// fits its LDS share, or one shared reference) and — checked by the caller — batch-shared bounds and no optional terms
+bool tile16_applies(const TinyBatch *tb)
+{
+    if (!tb->tile16_ok || tb->h16) return false;
+    if (tb->xref_mode == 1) return tb->table_rows <= tile16_max_table_rows();
+    return !tb->in_xref.set || tb->in_xref.shared;
+}
+
 int row_family(const TinyBatch *tb)
 {
     // one wavefront per instance: state on chip where the horizon fits (admm_waveres.hip, 6), else streamed through HBM (admm_wave.hip, 3)
@@ -759,9 +771,13 @@ int row_family(const TinyBatch *tb)
     // 5 = sixteen instances per wave, products on the matrix cores (admm_tile16.hip): on request only; needs fp32 storage and
     // a reference it does not have to keep resident (window of a table, or one shared reference)
     if (tb->row_family_forced == 5)
-        return (tb->tile16_ok && !tb->h16 && (tb->xref_mode == 1 || !tb->in_xref.set || tb->in_xref.shared)) ? 5 : (tb->row_dims_ok ? 0 : (tb->rowloop_ok ? 1 : 2));
+        return tile16_applies(tb) ? 5 : (tb->row_dims_ok ? 0 : (tb->rowloop_ok ? 1 : 2));
     if (tb->row_family_forced >= 0) return tb->row_family_forced;
     if (tb->quad_ok) return 4; // four lanes per instance (admm_quadlane.hip): nx = 4, nu = 1
+    // auto (round 3): sixteen instances per wave on the matrix cores where the launch is at least two rounds deep for its one
+    // wave per SIMD (2 048 tiles) — measured 1.79 against 1.91 ms on 65 536 tracking instances; smaller launches fill the chip
+    // better with four instances per wave, and a closed-loop run keeps the kernel whose MPC loop stays on chip
+    if (tile16_applies(tb) && !tb->closed_loop_run && tb->batch >= kTile16AutoBatch) return 5;
     if (tb->row_dims_ok) return 0;
     if (tb->rowloop_ok) return 1;
     return 2;
@@ -940,6 +956,7 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
         if (predicted_order) P.order = tb->order_buf;
         const int fam = row_family(tb);
         if (fam == 5 && !predicted_order) P.order = nullptr; // a caller's order lists groups of four instances, not tiles of sixteen
+        tb->last_dispatch = predicted_order ? 1 : (P.order ? 2 : 0);
         if (P.dual32 && fam != 0 && fam != 4)
             return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage with fp32 duals runs on the register-resident 16-lane and quad kernels only "
                                                  "(batch-shared bounds, no optional terms, no forced row kernel)");
@@ -1173,6 +1190,12 @@ int tiny_batch_set_dispatch(TinyBatch *tb, int mode)
     tb->dispatch_mode = mode;
     invalidate_graph(tb);
     return 0;
+}
+
+int tiny_batch_dispatch_applied(TinyBatch *tb)
+{
+    CHECK_TB(tb);
+    return tb->last_dispatch;
 }
 
 int tiny_batch_set_dispatch_order_device(TinyBatch *tb, const int *d_order)
@@ -1490,6 +1513,8 @@ int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, 
     TRY(flush_pending(tb)); // every solve of the run starts from "duals reset, workspace warm"
     tb->duals_zero_pending = true;
     int v = 0;
+    struct Scope { TinyBatch *t; ~Scope() { t->closed_loop_run = false; } } scope{tb};
+    tb->closed_loop_run = steps > 1;
     TRY(prepare_solve(tb, &v));
     const size_t u0n = (size_t)tb->batch * tb->nu;
     const int fam = v != VAR_STREAM ? row_family(tb) : -1;

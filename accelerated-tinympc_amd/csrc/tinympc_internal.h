@@ -139,6 +139,7 @@ hipError_t launch_admm_quadlane(int N, bool exact, bool h16, const RowParams &P,
 // instantiated horizons; ROW layout and RowParams of the row kernels; shared bounds, window / shared reference, fp32 storage
 bool tile16_supported(int nx, int nu, int N);
 hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t stream);
+int tile16_max_table_rows(); // rows of a trajectory table that fit the kernel's LDS share
 
 // wave-per-instance exact kernel (admm_wave.hip): 16 < nx + nu <= 64, any N, state in HBM, row width 64
 #define TINY_FOR_EACH_WAVEDIMS(X) X(32, 16) X(16, 8) X(16, 4) X(20, 8) X(24, 4)

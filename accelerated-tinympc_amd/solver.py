@@ -72,7 +72,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch_enable_timing": [P, C.c_int], "tiny_batch_last_solve_ms": [P, F],
         "tiny_batch_select_kernel": [P, C.c_int], "tiny_batch_set_storage": [P, C.c_int], "tiny_batch_set_storage_ex": [P, C.c_int, C.c_int],
         "tiny_batch_set_row_kernel": [P, C.c_int],
-        "tiny_batch_set_dispatch": [P, C.c_int], "tiny_batch_set_dispatch_order_device": [P, P],
+        "tiny_batch_set_dispatch": [P, C.c_int], "tiny_batch_set_dispatch_order_device": [P, P], "tiny_batch_dispatch_applied": [P],
         "tiny_batch_set_optional_terms": [P, C.c_int, C.c_int], "tiny_batch_set_input_cost": [P, F],
         "tiny_batch_set_coeff_d2p": [P, F], "tiny_batch_set_uref": [P, F, C.c_int],
         "tiny_batch_group_solve": [C.POINTER(P), C.c_int, I],
@@ -381,6 +381,10 @@ class TinyBatchSolver:
     def set_dispatch(self, mode: int):
         """0 = workgroups in index order, 1 = longest first by a predicted iteration count (register-resident row kernel)."""
         self._check(self.lib.tiny_batch_set_dispatch(self._h, mode))
+
+    def dispatch_applied(self) -> int:
+        """0 index order, 1 predicted longest first, 2 the caller's order — what the most recent solve launch did."""
+        return self._check(self.lib.tiny_batch_dispatch_applied(self._h))
 
     def set_dispatch_order_device(self, d_order_ptr):
         """Device pointer to a permutation of the ceil(batch/4) group indices (int32), or None."""

@@ -248,6 +248,9 @@ def main():
         step()
         kernel_ms.append(sol.last_solve_ms())
     n_unsolved = sol.wait()
+    # reported by the library for the launches just timed (tiny_batch_dispatch_applied), not re-derived here
+    dispatch_used = {0: "index order", 1: "longest first by predicted iteration count (predictor sweep + sort inside the timed region)",
+                     2: "caller-supplied order"}[sol.dispatch_applied()]
     iters, status, _ = sol.get_status()
     npar = min(B, 2048)
     gpu_u = sol.get_u()[:npar].copy() if (rank == 0 and world == 1 and not args.no_cpu) else None  # parity sample, before the extras touch the workspace
@@ -281,7 +284,7 @@ def main():
     extras_ok = rank == 0 and world == 1 and not args.kernel and args.config == "tracking"
     # the opt-in fma-chain arithmetic of the same kernel, for reference (not the headline: see DESIGN.md §3)
     fast = None
-    if extras_ok and sol.kernel_name().startswith("rowlane"):
+    if extras_ok and sol.kernel_name().startswith(("rowlane", "tile16")):
         sol.select_kernel(3)
         for _ in range(2):
             step()
@@ -444,8 +447,7 @@ def main():
                        "nx": NX, "nu": NU, "N": N, "instances_per_gpu": B, "instances_total": total, "parallelism": f"batch-shard x{world}",
                        "world_size_seen": world_seen, "backend": (backend if dist is not None else "none (single process)"),
                        "kernel": sol.kernel_name(),
-                       "dispatch": ("longest first by predicted iteration count (predictor sweep + sort inside the timed region)"
-                                    if args.dispatch and sol.kernel_name().startswith(("rowlane", "rowloop")) and B >= 16384 else "index order"),
+                       "dispatch": dispatch_used,
                        "mean_iters": agg["sum_iters"] / agg["n_instances"],
                        "max_iters": agg["max_iters"], "frac_converged": agg["n_converged"] / agg["n_instances"]},
             "roofline": roof,

@@ -210,8 +210,12 @@ extern "C"
      * few rounds deep and iteration counts are uneven, so what starts last decides when the launch ends; results never depend on the order).
      * mode 0 (default): index order.  mode 1: longest first by a predicted iteration count — one fma forward sweep over the first
      * eight horizon steps from the current workspace gives the largest primal residual per group of four instances, a bucket sort orders the groups;
-     * applied to launches of at least 4096 groups, a no-op elsewhere. */
+     * applied to launches of at least 4096 groups, a no-op elsewhere.  The 16-instances-per-wave kernel (tile16) orders its tiles of
+     * sixteen instances by the largest key of their four groups. */
     int tiny_batch_set_dispatch(TinyBatch *tb, int mode);
+    /* What the most recent solve launch actually did: 0 = index order (also when mode 1 did not apply: small launch, a kernel
+     * without dispatch order), 1 = longest first by the predicted iteration count, 2 = the caller's order. */
+    int tiny_batch_dispatch_applied(TinyBatch *tb);
     /* The caller's own order (e.g. from the iteration counts of the previous MPC step): d_order is a device array holding a
      * permutation of the ceil(batch/4) group indices, workgroup b solves instances 4*d_order[b] .. +3; it must stay valid
      * until the solves that use it have finished.  NULL returns to tiny_batch_set_dispatch's mode. */
