@@ -81,5 +81,20 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return LIB
 
 
+def device_asm(source: str) -> Path:
+    """gfx950 assembly listing of one kernel source, compiled with exactly the flags of build() (`hipcc -S --cuda-device-only`);
+    cached under lib/asm/ and redone when the source or a header is newer.  Used by tests/test_isa.py (static hazard and
+    register-spill guards over what the compiler actually emitted) and by the developer tools under tools/."""
+    src = CSRC / source
+    out = PKG / "lib" / "asm" / (Path(source).stem + ".s")
+    out.parent.mkdir(parents=True, exist_ok=True)
+    newest = max(d.stat().st_mtime for d in [src, Path(__file__), *HEADERS] if d.exists())
+    if not out.exists() or out.stat().st_mtime < newest:
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc, *[f for f in FLAGS if f != "-fPIC"], *EXTRA_FLAGS.get(source, []), "-S", "--cuda-device-only", str(src), "-o", str(out)]
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

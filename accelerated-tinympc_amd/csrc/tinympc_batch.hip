@@ -262,6 +262,7 @@ struct TinyBatch
     float *r_uref = nullptr;             // ROW derived: [batch_pad4 or 1][N][rw], Uref on the u rows
     const int *order_dev = nullptr;      // caller-owned dispatch order of the instance groups (tiny_batch_set_dispatch_order_device)
     int dispatch_mode = 0;               // tiny_batch_set_dispatch: 0 in index order, 1 longest first by the predicted iteration count
+    float *u0_stage = nullptr;           // [batch][nu] staging of u.col(0) for the peer copy of tiny_batch_group_gather_u0
     float *key_buf = nullptr;            // [groups] predictor of dispatch_order.hip
     int *order_buf = nullptr;            // [groups] its sorted order
     bool derived_dirty[2] = {true, true};
@@ -478,8 +479,7 @@ int store_input(TinyBatch *tb, InputArr &in, const float *host, bool shared, int
     in.set = true;
     if (shared) in.host.assign(host, host + n);
     else in.host.clear();
-    tb->derived_dirty[0] = tb->derived_dirty[1] = true;
-    invalidate_graph(tb); // shared <-> per-instance changes strides that a captured launch carries by value
+    tb->derived_dirty[0] = tb->derived_dirty[1] = true; // (a captured closed-loop graph carries the mode in its signature)
     return 0;
 }
 
@@ -1086,7 +1086,7 @@ void tiny_batch_destroy(TinyBatch *tb)
     free_layout(tb, LAYOUT_ROW);
     (void)hipFree(tb->in_xref.dev);
     (void)hipFree(tb->in_uref.dev); (void)hipFree(tb->r_uref);
-    (void)hipFree(tb->key_buf); (void)hipFree(tb->order_buf);
+    (void)hipFree(tb->key_buf); (void)hipFree(tb->order_buf); (void)hipFree(tb->u0_stage);
     for (int k = 0; k < 4; k++) { (void)hipFree(tb->in_bnd[k].dev); (void)hipFree(tb->t_bnd[k]); }
     (void)hipFree(tb->t_xref); (void)hipFree(tb->r_xref); (void)hipFree(tb->r_bounds);
     (void)hipFree(tb->tab_tile); (void)hipFree(tb->tab_row); (void)hipFree(tb->tab_row_h); (void)hipFree(tb->xref_start);
@@ -1103,8 +1103,8 @@ void tiny_batch_destroy(TinyBatch *tb)
 int tiny_batch_set_stream(TinyBatch *tb, void *hip_stream)
 {
     CHECK_TB(tb);
+    invalidate_graph(tb); // synchronises the stream a replay may still be running on: before that stream is replaced
     tb->stream = (hipStream_t)hip_stream;
-    invalidate_graph(tb);
     return 0;
 }
 
@@ -1216,8 +1216,7 @@ int tiny_batch_set_settings(TinyBatch *tb, float abs_pri_tol, float abs_dua_tol,
     tb->abs_pri_tol = abs_pri_tol; tb->abs_dua_tol = abs_dua_tol;
     tb->max_iter = max_iter; tb->check_termination = check_termination;
     tb->en_state_bound = en_state_bound; tb->en_input_bound = en_input_bound;
-    tb->have_settings = true;
-    invalidate_graph(tb); // tolerances, max_iter, check_termination and the bound flags are kernel arguments
+    tb->have_settings = true; // tolerances, max_iter, check_termination and the bound flags are in the graph signature
     return 0;
 }
 
@@ -1245,7 +1244,6 @@ int tiny_batch_set_xref(TinyBatch *tb, const float *xref, int shared)
     TRY(set_device(tb));
     TRY(store_input(tb, tb->in_xref, xref, shared != 0, tb->N, tb->nx));
     tb->xref_mode = 0;
-    invalidate_graph(tb);
     return 0;
 }
 
@@ -1358,6 +1356,66 @@ int tiny_batch_group_solve(TinyBatch **tbs, int n, int *n_unsolved)
     }
     if (n_unsolved) *n_unsolved = total;
     return total > 0 ? 1 : 0;
+}
+
+// Multi-device epilogue: handles that each own a block of the instance index (one handle per GPU, one
+// stream per handle) deliver u.col(0) of all their instances into ONE device buffer — handle order = block order.  Each
+// handle unpacks its first input column into a buffer of its own device and, where that is not the destination device, the
+// block travels device-to-device (hipMemcpyPeerAsync: xGMI between the GPUs of a node, no host staging), all copies in flight
+// together, one wait per handle at the end.  No collective: the path has none (the batch shards with no exchange step).
+int tiny_batch_group_gather_u0(TinyBatch **tbs, int n, int dst_device, float *d_dst)
+{
+    CHECK_PTR(tbs); CHECK_PTR(d_dst);
+    if (n < 1) return fail(TINY_BATCH_EINVAL, "tiny_batch_group_gather_u0: need at least one handle");
+    for (int i = 0; i < n; i++)
+    {
+        CHECK_TB(tbs[i]);
+        if (tbs[i]->nu != tbs[0]->nu) return fail(TINY_BATCH_EINVAL, "tiny_batch_group_gather_u0: handle %d has nu=%d, handle 0 nu=%d", i, tbs[i]->nu, tbs[0]->nu);
+    }
+    size_t off = 0;
+    for (int i = 0; i < n; i++)
+    {
+        TinyBatch *tb = tbs[i];
+        const size_t cnt = (size_t)tb->batch * tb->nu;
+        TRY(set_device(tb));
+        if (tb->device == dst_device)
+            TRY(launch_unpack(tb, work_ptr(tb, TINY_ARR_U), d_dst + off, tb->layout, 1, tb->batch, 0, 1)); // straight into its block
+        else
+        {
+            if (!tb->u0_stage) TRY(dev_alloc_zero(&tb->u0_stage, cnt));
+            TRY(launch_unpack(tb, work_ptr(tb, TINY_ARR_U), tb->u0_stage, tb->layout, 1, tb->batch, 0, 1));
+            HIP_TRY(hipMemcpyPeerAsync(d_dst + off, dst_device, tb->u0_stage, tb->device, cnt * sizeof(float), tb->stream));
+        }
+        off += cnt;
+    }
+    for (int i = 0; i < n; i++)
+    {
+        TRY(set_device(tbs[i]));
+        HIP_TRY(hipStreamSynchronize(tbs[i]->stream));
+    }
+    return 0;
+}
+
+// the same into host memory: gathered on the device of handle 0, then ONE device-to-host copy
+int tiny_batch_group_get_u0(TinyBatch **tbs, int n, float *u0_host)
+{
+    CHECK_PTR(tbs); CHECK_PTR(u0_host);
+    if (n < 1) return fail(TINY_BATCH_EINVAL, "tiny_batch_group_get_u0: need at least one handle");
+    size_t total = 0;
+    for (int i = 0; i < n; i++) { CHECK_TB(tbs[i]); total += (size_t)tbs[i]->batch * tbs[i]->nu; }
+    TRY(set_device(tbs[0]));
+    float *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, total * sizeof(float)));
+    int rc = tiny_batch_group_gather_u0(tbs, n, tbs[0]->device, d);
+    if (rc == 0)
+    {
+        (void)hipSetDevice(tbs[0]->device);
+        hipError_t e = hipMemcpy(u0_host, d, total * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(TINY_BATCH_EHIP, "tiny_batch_group_get_u0: %s", hipGetErrorString(e));
+    }
+    (void)hipSetDevice(tbs[0]->device);
+    (void)hipFree(d);
+    return rc;
 }
 
 int tiny_batch_forward_pass(TinyBatch *tb) { CHECK_TB(tb); return run_step(tb, STEP_FORWARD_PASS, nullptr, nullptr); }
@@ -1474,7 +1532,6 @@ int tiny_batch_set_xref_device(TinyBatch *tb, const float *d_xref, int shared)
     in.host.clear(); // only the bounds are ever read on the host
     tb->derived_dirty[0] = tb->derived_dirty[1] = true;
     tb->xref_mode = 0;
-    invalidate_graph(tb);
     return 0;
 }
 
@@ -1540,11 +1597,16 @@ int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, 
         tb->stream = tb->own_stream;
     }
     // the graph bakes in kernel arguments: rebuild it whenever anything they depend on may have changed
-    char sig[352];
-    snprintf(sig, sizeof sig, "%d|%d|%d|%s|%d|%d|%g|%g|%d|%d|%p|%p|%p|%d|%p|%p|%p|%p|%d%d", steps, window_advance, v, tb->kname.c_str(), tb->max_iter,
+    // (round 3: the signature is complete — rho, the shared / per-instance modes that set the strides, the bound flags and the
+    // dispatch order are in it — so setters that only change buffer CONTENTS no longer drop the graph: `set_xref; mpc_run(k)`
+    // in a loop replays one captured graph instead of re-capturing it every step)
+    char sig[480];
+    snprintf(sig, sizeof sig, "%d|%d|%d|%s|%d|%d|%g|%g|%d|%d|%p|%p|%p|%d|%p|%p|%p|%p|%d%d|%a|%d%d%d|%d%d|%d|%p|%p|%p", steps, window_advance, v, tb->kname.c_str(), tb->max_iter,
              tb->check_termination, (double)tb->abs_pri_tol, (double)tb->abs_dua_tol, tb->xref_mode, tb->table_rows, (void *)tb->pair[0],
              (void *)tb->arr[0], (void *)tb->r_bounds, (int)tb->h16, (void *)tb->stream, (void *)d_u0_traj, (void *)tb->r_xref,
-             (void *)tb->r_uref, (int)tb->en_uref, (int)tb->en_d2p);
+             (void *)tb->r_uref, (int)tb->en_uref, (int)tb->en_d2p, (double)tb->rho, (int)bounds_all_shared(tb),
+             (int)(tb->in_xref.set && tb->in_xref.shared), (int)(tb->in_uref.set && tb->in_uref.shared), tb->en_state_bound, tb->en_input_bound,
+             tb->dispatch_mode, (void *)tb->order_dev, (void *)tb->mats_exact, (void *)tb->xref_start);
     if (!tb->graph_exec || tb->graph_sig != sig)
     {
         if (tb->graph_exec) { (void)hipGraphExecDestroy(tb->graph_exec); tb->graph_exec = nullptr; }
@@ -1575,6 +1637,27 @@ int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, 
 int tiny_batch_mpc_run_async(TinyBatch *tb, int steps, int window_advance)
 {
     return tiny_batch_mpc_run_traj_async(tb, steps, window_advance, nullptr);
+}
+
+// host-copy variant: the trajectory buffer is allocated on the HANDLE's device (whatever device is current for the calling
+// thread), the run is waited for and u.col(0) of every step lands in host memory
+int tiny_batch_mpc_run_traj(TinyBatch *tb, int steps, int window_advance, float *u0_traj_host)
+{
+    CHECK_TB(tb); CHECK_PTR(u0_traj_host);
+    if (steps < 1) return fail(TINY_BATCH_EINVAL, "tiny_batch_mpc_run_traj: steps must be >= 1");
+    TRY(set_device(tb));
+    const size_t n = (size_t)steps * tb->batch * tb->nu;
+    float *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, n * sizeof(float)));
+    int rc = tiny_batch_mpc_run_traj_async(tb, steps, window_advance, d);
+    if (rc == 0)
+    {
+        hipError_t e = hipStreamSynchronize(tb->stream);
+        if (e == hipSuccess) e = hipMemcpy(u0_traj_host, d, n * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(TINY_BATCH_EHIP, "tiny_batch_mpc_run_traj: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    return rc;
 }
 
 int tiny_batch_get_x0(TinyBatch *tb, float *x0)

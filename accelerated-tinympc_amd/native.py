@@ -61,7 +61,9 @@ def load_wrapper_library(build_if_missing: bool = False, double: bool = False) -
     if double:
         if _lib64 is None:
             if not WRAPPER64_LIB_PATH.exists():
-                raise RuntimeError(f"{WRAPPER64_LIB_PATH} is missing: run `python accelerated-tinympc_amd/build.py`")
+                if not build_if_missing:
+                    raise RuntimeError(f"{WRAPPER64_LIB_PATH} is missing: run `python accelerated-tinympc_amd/build.py`")
+                _build.build()
             lib = C.CDLL(str(WRAPPER64_LIB_PATH))
             S = C.POINTER(TYPES64[3])
             lib.tiny_solve.argtypes, lib.tiny_solve.restype = [S], C.c_int

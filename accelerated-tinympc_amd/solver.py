@@ -43,7 +43,11 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
             raise TinyBatchError(f"{LIB_PATH} is missing: run `python accelerated-tinympc_amd/build.py` "
                                  "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     # developer aid: TINYMPC_HIP_LIB names another build of the SAME library (tools/ab_kernels.py times kernel variants)
-    lib = C.CDLL(os.environ.get("TINYMPC_HIP_LIB") or str(LIB_PATH))
+    override = os.environ.get("TINYMPC_HIP_LIB")
+    if override:
+        import warnings
+        warnings.warn(f"TINYMPC_HIP_LIB is set: loading {override} instead of {LIB_PATH}", RuntimeWarning)
+    lib = C.CDLL(override or str(LIB_PATH))
     F, I, P = C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p
     D = C.POINTER(C.c_double)
     sig = {
@@ -68,7 +72,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch_reset_workspace": [P],
         "tiny_batch_set_x0_device": [P, P], "tiny_batch_get_u0_device": [P, P],
         "tiny_batch_mpc_step_async": [P, C.c_int], "tiny_batch_get_x0": [P, F],
-        "tiny_batch_mpc_run_async": [P, C.c_int, C.c_int], "tiny_batch_mpc_run_traj_async": [P, C.c_int, C.c_int, P],
+        "tiny_batch_mpc_run_async": [P, C.c_int, C.c_int], "tiny_batch_mpc_run_traj_async": [P, C.c_int, C.c_int, P], "tiny_batch_mpc_run_traj": [P, C.c_int, C.c_int, F],
         "tiny_batch_enable_timing": [P, C.c_int], "tiny_batch_last_solve_ms": [P, F],
         "tiny_batch_select_kernel": [P, C.c_int], "tiny_batch_set_storage": [P, C.c_int], "tiny_batch_set_storage_ex": [P, C.c_int, C.c_int],
         "tiny_batch_set_row_kernel": [P, C.c_int],
@@ -76,6 +80,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch_set_optional_terms": [P, C.c_int, C.c_int], "tiny_batch_set_input_cost": [P, F],
         "tiny_batch_set_coeff_d2p": [P, F], "tiny_batch_set_uref": [P, F, C.c_int],
         "tiny_batch_group_solve": [C.POINTER(P), C.c_int, I],
+        "tiny_batch_group_gather_u0": [C.POINTER(P), C.c_int, C.c_int, P], "tiny_batch_group_get_u0": [C.POINTER(P), C.c_int, F],
         "tiny_batch_set_array_device": [P, C.c_int, P], "tiny_batch_get_array_device": [P, C.c_int, P],
         "tiny_batch_set_xref_device": [P, P, C.c_int],
         "tiny_riccati": [C.c_int, C.c_int, D, D, D, D, C.c_double, D, D, D, D, D, I],
@@ -335,20 +340,10 @@ class TinyBatchSolver:
         self._check(self.lib.tiny_batch_mpc_run_async(self._h, steps, window_advance))
 
     def mpc_run_traj(self, steps: int, window_advance: int = 0) -> np.ndarray:
-        """tiny_batch_mpc_run_traj_async + copy-out: runs `steps` closed-loop MPC steps and returns u.col(0) of every step,
-        shape (steps, B, nu).  The trajectory buffer lives in device memory for the duration of the call."""
-        hip = C.CDLL("libamdhip64.so")
+        """tiny_batch_mpc_run_traj: runs `steps` closed-loop MPC steps and returns u.col(0) of every step, shape (steps, B, nu).
+        The library allocates the device-side trajectory buffer on this handle's own device."""
         out = np.zeros((steps, self.B, self.nu), np.float32)
-        d = C.c_void_p()
-        if hip.hipMalloc(C.byref(d), C.c_size_t(out.nbytes)) != 0:
-            raise TinyBatchError("hipMalloc of the trajectory buffer failed")
-        try:
-            self._check(self.lib.tiny_batch_mpc_run_traj_async(self._h, steps, window_advance, d))
-            self.synchronize()
-            if hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), d, C.c_size_t(out.nbytes), 2) != 0:
-                raise TinyBatchError("hipMemcpy of the trajectory buffer failed")
-        finally:
-            hip.hipFree(d)
+        self._check(self.lib.tiny_batch_mpc_run_traj(self._h, steps, window_advance, _fp(out)))
         return out
 
     def get_x0(self):
@@ -374,8 +369,9 @@ class TinyBatchSolver:
         self._check(self.lib.tiny_batch_select_kernel(self._h, variant))
 
     def set_row_kernel(self, family: int):
-        """0 auto, 1 rowlane (unrolled), 2 rowloop (rolled, N <= 32), 3 rowstream (state in HBM), 4 quadlane (nx=4, nu=1),
-        5 tile16 (16 instances per wave, products on the matrix cores; nx=12, nu=4, instantiated N)."""
+        """0 auto, 1 rowlane (unrolled), 2 rowloop (rolled, N <= 64), 3 rowstream (state in HBM), 4 quadlane (nx=4, nu=1),
+        5 tile16 (16 instances per wave, products on the matrix cores; nx=12, nu=4, instantiated N; the auto choice for launches
+        of >= 32768 instances), 6 wavestream / 7 waveres (one wavefront per instance, 16 < nx + nu <= 64)."""
         self._check(self.lib.tiny_batch_set_row_kernel(self._h, family))
 
     def set_dispatch(self, mode: int):

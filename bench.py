@@ -73,7 +73,17 @@ def kernel_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(prob, make_batch, seconds_target=12.0):
+def cpu_model() -> str:
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(prob, make_batch, settings, seconds_target=12.0, fixed10_n=0):
     """Time the reference's own CPU path (oracle/_ref, compiled Eigen code, 1 thread — it is single threaded) or,
     if that prebuilt library is absent, our C port (oracle/), on a bounded sample of the same workload.
     `make_batch(nb)` -> (x0, Xref) of the FIRST nb instances of the benchmarked batch.  Returns the JSON object and the
@@ -84,7 +94,7 @@ def cpu_baseline(prob, make_batch, seconds_target=12.0):
     nx, nu, N = prob["nx"], prob["nu"], prob["N"]
     xmn, xmx, umn, umx = pr.bounds_arrays(prob)
     kind = "reference" if O.have_ref(np.float32, nx, nu, N) else "port"
-    solver = (O.Reference if kind == "reference" else O.Oracle)(prob, np.float32)
+    solver = (O.Reference if kind == "reference" else O.Oracle)(prob, np.float32, settings)  # the settings of the benchmarked run
 
     def run(nb, cls_solver, nthreads=1):
         x0, xr = make_batch(nb)
@@ -106,19 +116,30 @@ def cpu_baseline(prob, make_batch, seconds_target=12.0):
     t_probe, _ = run(64, solver)
     chunk = int(min(32768, max(64, 64 * 2.0 / max(t_probe, 1e-6))))
     nb, t, mi, first = timed(solver, 1, seconds_target, chunk)
-    out = dict(value=nb / t, unit="solves/s", cores=1, kind=kind,
-               sample=f"{nb} cold-start tiny_solve calls on the first instances of the same workload ({chunk}-instance passes), "
-                      f"{t:.1f} s, mean {mi:.1f} iterations, FTZ/DAZ off, g++ -O3 SSE2 (the build SURVEY.md probed)")
-    # our multi-threaded C port on the host cores this process may use, for scale (not what the reference ships)
     try:
         ncores = len(os.sched_getaffinity(0))
     except AttributeError:
         ncores = os.cpu_count() or 1
-    ncores = max(1, min(ncores, 16))
-    port = O.Oracle(prob, np.float32)
+    out = dict(value=nb / t, unit="solves/s", cores=1, kind=kind, cpu_model=cpu_model(), host_cores_visible=ncores,
+               sample=f"{nb} cold-start tiny_solve calls on the first instances of the same workload ({chunk}-instance passes), "
+                      f"{t:.1f} s, mean {mi:.1f} iterations, FTZ/DAZ off",
+               build="g++ -O3, SSE2 (x86-64 baseline, no -march=native): the parity build of the reference (the one whose bits the "
+                     "GPU kernels reproduce), not the fastest CPU build of it")
+    # our multi-threaded C port on every host core this process may use, for scale (not what the reference ships)
+    ncores = max(1, ncores)
+    port = O.Oracle(prob, np.float32, settings)
     nbp, tp, _, _ = timed(port, ncores, 4.0, max(64, min(4096, chunk)) * ncores)
-    out["port_all_cores"] = dict(value=nbp / tp, unit="solves/s", cores=ncores, kind="port",
-                                 sample=f"{nbp} solves, OpenMP over instances, {tp:.1f} s")
+    out["port_all_cores"] = dict(value=nbp / tp, unit="solves/s", cores=ncores, kind="port", cpu_model=cpu_model(),
+                                 sample=f"{nbp} solves, OpenMP over instances, {tp:.1f} s", build="gcc -O3 -march=native -fopenmp (oracle/Makefile)")
+    # the same first instances at a FIXED iteration count (tolerances 0, 10 iterations): the checker's side of the fma-mode
+    # parity figure (SURVEY.md section 7 "Parity definition" (i)); not timed
+    if fixed10_n:
+        fs = dict(settings, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=10)
+        x0, xr = make_batch(fixed10_n)
+        st10 = O.new_state(fixed10_n, nx, nu, N)
+        st10["x"][:, 0] = x0
+        (O.Reference if kind == "reference" else O.Oracle)(prob, np.float32, fs).solve(st10, xmn, xmx, umn, umx, xr, nthreads=1)
+        first = dict(first, u_fixed10=st10["u"])
     return out, first, kind
 
 
@@ -132,6 +153,31 @@ def parity_of(gpu_u, gpu_iter, gpu_status, ref, kind, u_scale):
     return dict(instances=int(n), max_rel_u=float(rel.max()), bitwise_u=bool(np.array_equal(gpu_u[:n], ref["u"][:n])),
                 iter_mismatch=int(np.sum(gpu_iter[:n] != ref["iter"][:n])), status_mismatch=int(np.sum(gpu_status[:n] != ref["status"][:n])),
                 against=f"cpu_baseline ({kind}) on the same inputs, whole horizon of u")
+
+
+def fma_parity(fast, ref_first, kind, u_scale):
+    """The fma-chain mode against the compiled reference (or the port) on the first instances of the batch; the reference's
+    results come from the cpu_baseline leg.  Two figures, SURVEY.md section 7 'Parity definition': (i) at a fixed iteration
+    count (tolerances 0, 10 iterations) u can be compared instance by instance; (ii) with early exit the iteration count
+    itself may flip where a residual sits at the tolerance, so u is compared over the instances whose count agrees and the
+    flip fraction is reported next to it."""
+    n = min(fast["_u_early_exit"].shape[0], ref_first["u"].shape[0])
+
+    def rel(g, r):
+        g, r = g.astype(np.float64).reshape(len(g), -1), r.astype(np.float64).reshape(len(r), -1)
+        return np.max(np.abs(g - r), axis=1) / np.maximum(np.max(np.abs(r), axis=1), u_scale)
+
+    same = fast["_iter_early_exit"][:n] == ref_first["iter"][:n]
+    out = {"instances": int(n), "against": f"cpu_baseline ({kind}) on the same inputs, whole horizon of u; normalised by max(|u_ref|_inf, input bound)",
+           "early_exit": {"iter_flip_fraction": float(np.mean(~same)),
+                          "max_rel_u_same_iteration_count": float(rel(fast["_u_early_exit"][:n][same], ref_first["u"][:n][same]).max()) if same.any() else None,
+                          "max_rel_u_all": float(rel(fast["_u_early_exit"][:n], ref_first["u"][:n]).max())}}
+    if "u_fixed10" in ref_first:
+        m = min(n, ref_first["u_fixed10"].shape[0])
+        r10 = rel(fast["_u_fixed10"][:m], ref_first["u_fixed10"][:m])
+        out["fixed_10_iterations"] = {"instances": int(m), "max_rel_u": float(r10.max()), "p99_rel_u": float(np.percentile(r10, 99)),
+                                      "north_star_tolerance": 1e-5, "within_1e-5": bool(r10.max() <= 1e-5)}
+    return out
 
 
 def main():
@@ -156,9 +202,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here, BEFORE torch or HIP is touched in this process
+        # (one process per GPU; the children are what the documented torch.distributed.run command would start), forward rank
+        # 0's JSON line and the launcher's return code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     if args.gpus != world:
-        # one process per GPU: N > 1 is launched by torch.distributed.run (see the module docstring); a lone process asked
-        # for N GPUs would silently measure one
+        # inside an already launched group the two must agree: a lone rank asked for N GPUs would silently measure one
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 as\n  python -m torch.distributed.run --nnodes=1 "
                          f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...\n")
         raise SystemExit(2)
@@ -278,7 +335,7 @@ def main():
             gather = {"op": "all_gather of u.col(0)", "bytes_per_rank": cap * NU * 4, "ms": (time.perf_counter() - t_g) * 1e3,
                       "own_block_intact": bool(torch.equal(mine, d_u0[:B]))}
         except Exception as e:  # noqa: BLE001
-            gather = {"error": f"{type(e).__name__}: {e}"}
+            gather = {"error": f"{type(e).__name__}: {e}"}  # reported in the line AND, with more than one rank, as exit code 3 below
     total_solves = total * args.steps
     value = total_solves / dt
     extras_ok = rank == 0 and world == 1 and not args.kernel and args.config == "tracking"
@@ -296,6 +353,14 @@ def main():
         fast = dict(kernel=sol.kernel_name(), kernel_ms=float(np.mean(ms)), solves_per_s=B / (float(np.mean(ms)) * 1e-3),
                     f32_frac=cost.flops_of(itf, stf) / (float(np.mean(ms)) * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                     mean_iters=float(itf.mean()), note="kernel time only; parity bar = the reference's own fp64/fp32 spread")
+        if not args.no_cpu:
+            fast["_u_early_exit"] = sol.get_u()[:npar].copy()
+            fast["_iter_early_exit"] = itf[:npar].copy()
+            # the same instances at a FIXED iteration count (tolerances 0, 10 iterations: SURVEY.md section 7 "Parity definition" (i))
+            sol.set_settings(**dict(settings, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=10))
+            step(); sol.synchronize()
+            fast["_u_fixed10"] = sol.get_u()[:npar].copy()
+            sol.set_settings(**settings)
         sol.select_kernel(0)
 
     # warm-started closed loop (how the reference's examples actually run the solver, quadrotor_tracking.cpp:93-118):
@@ -463,14 +528,26 @@ def main():
         if fp64 is not None:
             line["fp64_tinytype"] = fp64
         if not args.no_cpu and world == 1:  # rank 0 at N=1 only: the other ranks of a multi-GPU run would sit in the barrier
-            cb, ref_first, kind = cpu_baseline(prob, make_batch)
+            cb, ref_first, kind = cpu_baseline(prob, make_batch, settings, fixed10_n=(npar if (fast is not None and "_u_fixed10" in fast) else 0))
             line["cpu_baseline"] = cb
-            line["parity"] = parity_of(gpu_u, iters, status, ref_first, kind, max(abs(prob["u_max"]), abs(prob["u_min"])))
+            u_scale = max(abs(prob["u_max"]), abs(prob["u_min"]))
+            line["parity"] = parity_of(gpu_u, iters, status, ref_first, kind, u_scale)
+            if fast is not None and "_u_early_exit" in fast:
+                line["fast_arithmetic"]["parity"] = fma_parity(fast, ref_first, kind, u_scale)
+        if fast is not None:
+            for k in [k for k in fast if k.startswith("_")]:
+                del fast[k]
         print(json.dumps(line), flush=True)
     sol.close()
+    gather_failed = isinstance(gather, dict) and ("error" in gather or gather.get("own_block_intact") is False)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            gather_failed = True
+    if gather_failed and world > 1:
+        raise SystemExit(3)  # the collective epilogue failed on this rank: the scaling run must not pass silently
 
 
 if __name__ == "__main__":

@@ -133,6 +133,15 @@ extern "C"
      * is moved to a stream of its own), so the classes overlap on the device.  Returns 0 if every instance of every
      * handle converged, 1 if some hit max_iter (*n_unsolved = how many, may be NULL), negative on error. */
     int tiny_batch_group_solve(TinyBatch **tbs, int n, int *n_unsolved);
+    /* ---- one node, several GPUs: one handle per device, each owning a contiguous block of the instance index ----
+     * (the batch shards with no data-path collective; one host thread drives all devices through the
+     * handles' streams.)  tiny_batch_group_solve above launches every handle's solve on its own device before waiting for any.
+     * The optional epilogue: u.col(0) (the control actually applied, nu floats per instance) of every handle, in handle order,
+     * into ONE device buffer on dst_device ([sum of batches][nu]); blocks of other devices travel device to device
+     * (hipMemcpyPeerAsync, xGMI inside a node), all in flight together.  Returns when the buffer is complete. */
+    int tiny_batch_group_gather_u0(TinyBatch **tbs, int n, int dst_device, float *d_dst);
+    /* the same into host memory (gathered on the device of handle 0, then one device-to-host copy) */
+    int tiny_batch_group_get_u0(TinyBatch **tbs, int n, float *u0_host);
 
     /* ---- whole-workspace access (warm-start upload, parity tests) ---------------------------- */
     int tiny_batch_set_array(TinyBatch *tb, int array_id, const float *src);
@@ -162,6 +171,9 @@ extern "C"
      * The _traj form also records u.col(0) of every step into a DEVICE buffer [steps][B][nu]. */
     int tiny_batch_mpc_run_async(TinyBatch *tb, int steps, int window_advance);
     int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, float *d_u0_traj);
+    /* The same, blocking, with the trajectory in HOST memory ([steps][batch][nu]): the device buffer is allocated on the
+     * handle's own device, whatever device is current for the calling thread. */
+    int tiny_batch_mpc_run_traj(TinyBatch *tb, int steps, int window_advance, float *u0_traj_host);
     int tiny_batch_get_x0(TinyBatch *tb, float *x0 /*[B][nx]*/);
 
     /* ---- measurement ------------------------------------------------------------------------- */

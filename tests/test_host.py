@@ -123,6 +123,11 @@ def test_cpp_example_compiles_and_links_against_the_c_abi(tinympc, tmp_path):
                         f"-Wl,-rpath,{lib_dir}", "-o", str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert (ROOT / "accelerated-tinympc_amd" / "data" / "quadrotor_20hz.bin").stat().st_size == 557 * 8
+    # the multi-device example (one handle per GPU, group solve, device-to-device gather) is the C-ABI only as well
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", f"-I{ROOT / 'include'}",
+                        str(ROOT / "examples" / "quadrotor_tracking_multigpu.cpp"), f"-L{lib_dir}", "-ltinympc_hip",
+                        f"-Wl,-rpath,{lib_dir}", "-o", str(tmp_path / "multigpu")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
     # the hovering example over the reference's own names (include/tinympc_admm.h) links against the wrapper library
     r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", f"-I{ROOT / 'include'}",
                         str(ROOT / "examples" / "quadrotor_hovering_native.cpp"), f"-L{lib_dir}", "-ltinympc_wrapper",

@@ -2213,3 +2213,53 @@ def test_fp64_vs_oracle(tinympc, oracle_mod, nx, nu, N, kernel):
         sol.close()
     with pytest.raises(tinympc.TinyBatchError):
         tinympc.TinyBatchSolver64(dict(prob, nx=5), 4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one node, several GPUs, from C++ through the C-ABI (one host thread, one handle + stream per device)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,devices", [(4096, "0,0"), (1000, "0,0,0"), (37, "0,0"), (40000, "0,0")])
+def test_cpp_multi_device_example_equals_the_single_handle_solve(tinympc, tmp_path, B, devices):
+    """examples/quadrotor_tracking_multigpu.cpp: the batch block-sharded over several handles (one per listed device; on a
+    one-GPU box two or three handles on device 0, which exercises the same code: per-handle set_device, group solve, the
+    gather of u.col(0) into one device buffer), compared by the program itself with ONE handle solving the whole batch: u.col(0),
+    iteration counts and status bit for bit.  With every visible GPU listed it is the RCCL-free multi-GPU path of the C++ host."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    lib_dir = root / "accelerated-tinympc_amd" / "lib"
+    exe = tmp_path / "multigpu"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", f"-I{root / 'include'}", str(root / "examples" / "quadrotor_tracking_multigpu.cpp"),
+                        f"-L{lib_dir}", "-ltinympc_hip", f"-Wl,-rpath,{lib_dir}", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe), str(root / "accelerated-tinympc_amd" / "data" / "quadrotor_20hz.bin"), str(B), devices],
+                       capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "sharded == single handle, bit for bit" in r.stdout
+
+
+def test_group_gather_u0_from_python(tinympc):
+    """tiny_batch_group_gather_u0 / _get_u0 through ctypes: three handles of different sizes, blocks in handle order."""
+    import ctypes as C
+    pr = tinympc.problems
+    prob = pr.quadrotor(20, 30)
+    sizes = [100, 7, 333]
+    x0, table, start = pr.tracking_batch(sum(sizes), 30, seed=5)
+    sols, off = [], 0
+    for n in sizes:
+        s = tinympc.TinyBatchSolver(prob, n)
+        s.set_bounds(*pr.bounds_arrays(prob)); s.set_xref_window(table, start[off:off + n]); s.set_x0(x0[off:off + n])
+        sols.append(s); off += n
+    tinympc.solve_group(sols)
+    lib = sols[0].lib
+    hs = (C.c_void_p * len(sols))(*[s._h for s in sols])
+    out = np.zeros((sum(sizes), 4), np.float32)
+    assert lib.tiny_batch_group_get_u0(hs, len(sols), out.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    want = np.concatenate([s.get_u()[:, 0] for s in sols])
+    assert np.array_equal(out, want)
+    for s in sols:
+        s.close()
