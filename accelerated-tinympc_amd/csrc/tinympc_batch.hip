@@ -1710,7 +1710,15 @@ int tiny_batch_set_row_kernel(TinyBatch *tb, int family)
     return 0;
 }
 
-int tiny_batch_set_storage(TinyBatch *tb, int bits) { return tiny_batch_set_storage_ex(tb, bits, bits); }
+// bits = 16: the duals stay fp32 wherever the kernels implement that (round 3: with 16-bit duals a quarter of a cartpole batch and
+// 8 % of a quadrotor batch stall above the tolerances; 16-bit duals remain available through tiny_batch_set_storage_ex(tb, 16, 16)
+// and are what the kernels that stream their state implement)
+int tiny_batch_set_storage(TinyBatch *tb, int bits)
+{
+    CHECK_TB(tb);
+    const bool d32 = bits == 16 && (tb->row_dims_ok || tb->quad_ok);
+    return tiny_batch_set_storage_ex(tb, bits, d32 ? 32 : bits);
+}
 
 int tiny_batch_set_storage_ex(TinyBatch *tb, int bits, int dual_bits)
 {

@@ -114,7 +114,8 @@ struct RowParams
 };
 
 // (nx, nu) pairs with single-function kernels (admm_steps.hip), any N
-#define TINY_FOR_EACH_ROWDIMS(X) X(12, 4) X(4, 1) X(8, 3) X(8, 4) X(12, 2) X(4, 2) X(4, 4)
+// (2, 2): the reference's own examples/codegen_random.cpp:19-31 (n = 2, m = 2, N = 3, min > max bounds)
+#define TINY_FOR_EACH_ROWDIMS(X) X(12, 4) X(4, 1) X(8, 3) X(8, 4) X(12, 2) X(4, 2) X(4, 4) X(2, 2)
 enum { STEP_FORWARD_PASS = 0, STEP_UPDATE_SLACK, STEP_UPDATE_DUAL, STEP_UPDATE_LINEAR_COST, STEP_TERMINATION_CONDITION,
        STEP_BACKWARD_PASS_GRAD };
 

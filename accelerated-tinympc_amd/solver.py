@@ -387,9 +387,13 @@ class TinyBatchSolver:
         self._check(self.lib.tiny_batch_set_dispatch_order_device(self._h, C.c_void_p(d_order_ptr)))
 
     def set_storage(self, bits: int, dual_bits: int | None = None):
-        """32 = fp32 work arrays (default); 16 = IEEE binary16 storage with fp32 arithmetic; dual_bits=32 with bits=16 keeps
-        the duals y, g in fp32.  Restarts the workspace."""
-        self._check(self.lib.tiny_batch_set_storage_ex(self._h, bits, bits if dual_bits is None else dual_bits))
+        """tiny_batch_set_storage(bits) when dual_bits is None — for bits = 16 that is binary16 storage with the duals y, g kept in
+        fp32 wherever the class has a register-resident kernel (the variant that converges), 16-bit duals
+        elsewhere; tiny_batch_set_storage_ex(bits, dual_bits) otherwise ((16, 16): everything binary16)."""
+        if dual_bits is None:
+            self._check(self.lib.tiny_batch_set_storage(self._h, bits))
+        else:
+            self._check(self.lib.tiny_batch_set_storage_ex(self._h, bits, dual_bits))
 
     def set_stream(self, stream_ptr: int):
         self._check(self.lib.tiny_batch_set_stream(self._h, C.c_void_p(stream_ptr)))

@@ -83,6 +83,28 @@ def cpu_model() -> str:
     return "unknown"
 
 
+def usable_cores() -> int:
+    """Host cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota where one is set (a GPU box
+    hands a job a share of a large host: 256 visible cores, 16 of them usable)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(f).read().split()
+            if f.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(prob, make_batch, settings, seconds_target=12.0, fixed10_n=0):
     """Time the reference's own CPU path (oracle/_ref, compiled Eigen code, 1 thread — it is single threaded) or,
     if that prebuilt library is absent, our C port (oracle/), on a bounded sample of the same workload.
@@ -98,6 +120,8 @@ def cpu_baseline(prob, make_batch, settings, seconds_target=12.0, fixed10_n=0):
 
     def run(nb, cls_solver, nthreads=1):
         x0, xr = make_batch(nb)
+        nb = len(x0)  # the batch has no more instances than that (many host cores x the per-core chunk can exceed it)
+        xr = xr[:nb] if getattr(xr, "ndim", 2) == 3 else xr
         st = O.new_state(nb, nx, nu, N)
         st["x"][:, 0] = x0
         t0 = time.perf_counter()
@@ -110,17 +134,15 @@ def cpu_baseline(prob, make_batch, settings, seconds_target=12.0, fixed10_n=0):
         while t < budget_s:
             dt, st = run(chunk, solver_, nthreads)
             first = st if first is None else first
-            n += chunk; t += dt; its.append(st["iter"].mean())
+            n += len(st["iter"]); t += dt; its.append(st["iter"].mean())
         return n, t, float(np.mean(its)), first
 
     t_probe, _ = run(64, solver)
     chunk = int(min(32768, max(64, 64 * 2.0 / max(t_probe, 1e-6))))
     nb, t, mi, first = timed(solver, 1, seconds_target, chunk)
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncores = os.cpu_count() or 1
-    out = dict(value=nb / t, unit="solves/s", cores=1, kind=kind, cpu_model=cpu_model(), host_cores_visible=ncores,
+    ncores = usable_cores()
+    out = dict(value=nb / t, unit="solves/s", cores=1, kind=kind, cpu_model=cpu_model(), host_cores_usable=ncores,
+               host_cores_visible=(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()),
                sample=f"{nb} cold-start tiny_solve calls on the first instances of the same workload ({chunk}-instance passes), "
                       f"{t:.1f} s, mean {mi:.1f} iterations, FTZ/DAZ off",
                build="g++ -O3, SSE2 (x86-64 baseline, no -march=native): the parity build of the reference (the one whose bits the "

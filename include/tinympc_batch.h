@@ -207,7 +207,10 @@ extern "C"
      * 32 = fp32 like the reference (default); 16 = IEEE binary16 storage with fp32 arithmetic (BASELINE.json
      * configs[4]): every assignment to a work array rounds to nearest even, products, sums and the four residual
      * reductions stay fp32.  Row kernels only (nx + nu <= 16, batch-shared bounds).  Host-side arrays stay float; values
-     * are rounded when they are stored.  Changing the precision restarts the workspace from zero, like create. */
+     * are rounded when they are stored.  Changing the precision restarts the workspace from zero, like create.
+     * With bits = 16 the DUALS y, g stay fp32 where the class has a register-resident kernel instantiation (= set_storage_ex(tb,
+     * 16, 32): "fp16 states with fp32 residual accumulation" — with 16-bit duals part of a batch stalls short of the tolerances,
+     * see below); classes without one get 16-bit duals.  tiny_batch_set_storage_ex(tb, 16, 16) forces binary16 everywhere. */
     int tiny_batch_set_storage(TinyBatch *tb, int bits);
     /* The same with the precision of the DUALS y, g chosen separately: (32, 32) and (16, 16) are tiny_batch_set_storage;
      * (16, 32) keeps the duals — the running sums of the primal residuals, admm.cpp:69-70 — in fp32 while the other ten

@@ -101,7 +101,7 @@ while time.time() < t_end:
             if sol.kernel_name().startswith("stream"):
                 sol.select_kernel(2)
             h16 = not h16
-            sol.set_storage(16 if h16 else 32)
+            sol.set_storage(16 if h16 else 32, 16 if h16 else 32)
             R = O.round_h16 if h16 else (lambda a: a)
             orc = new_oracle()
             for k in O.STATE_ORDER + ("residuals", "status", "iter"):

@@ -66,7 +66,7 @@ while time.time() < t_end:
     h16 = not wave and rng.random() < 0.3   # fp16 storage / fp32 arithmetic against the oracle's _h16 restatement
     h16d = False
     if h16:
-        sol.set_storage(16)
+        sol.set_storage(16, 16)
         if rng.random() < 0.4:   # ... with the duals kept in fp32 (register-resident kernels only; refused elsewhere)
             try:
                 sol.set_storage(16, 32); h16d = True

@@ -15,6 +15,9 @@ Scenarios:
   cartpole_f32_N10     examples/codegen_cartpole.cpp model, gains from the reference's tiny_codegen()
   random_f32_32_16_50  seeded nx=32,nu=16 system, gains from tiny_codegen(), 2 solves x 4 instances
   dims_f32_8_3_7       odd sizes (nx, nu not multiples of 4), random stable system
+  codegen_random_f32_2_2_3  the problem of examples/codegen_random.cpp:19-31 (n = 2, m = 2, N = 3, rho = 0.1, x_min > x_max and
+                       u_min > u_max — infeasible boxes, per-row values), gains from the reference's tiny_codegen(); 24 instances,
+                       three chained solves, bounds stored as full arrays (bnd_*)
   riccati_*            reference tiny_codegen() cache for cartpole and the random system
   closed_loop_traces   whole closed loops of the compiled reference (tiny_solve + the examples' Eigen plant step) over
                        batches of 64 (20) instances: u.col(0), iter, status of EVERY step and the final x0 — hovering 70
@@ -205,6 +208,39 @@ def main():
     save("dims_f32_8_3_7", od, np.float32, S, recs)
 
 
+def codegen_random_fixture():
+    """examples/codegen_random.cpp:19-31: the numbers are the example's (column-major in the source), the cache is what the
+    reference's own tiny_codegen() emits for them."""
+    nx, nu, N = 2, 2, 3
+    A = np.array([[1.0, 1.0], [5.0, 2.0]])       # Adyn_data = {1, 5, 1, 2} column-major
+    Bm = np.array([[3.0, 4.0], [3.0, 1.0]])      # Bdyn_data = {3, 3, 4, 1}
+    Q, R, rho = np.array([1.0, 1.0]), np.array([2.0, 2.0]), 0.1
+    txt, _ = ref_riccati(nx, nu, N, A, Bm, Q, R, rho)
+    rho_c, K, P, Qi, Am = parse_cache(txt, nx, nu)
+    # work.Q as tiny_codegen stores it: Q + rho (codegen.cpp:255, :433)
+    prob = dict(nx=nx, nu=nu, N=N, rho=rho_c, Kinf=K, Pinf=P, Quu_inv=Qi, AmBKt=Am, Adyn=A, Bdyn=Bm, Q=Q + rho,
+                x_min=0.0, x_max=0.0, u_min=0.0, u_max=0.0)
+    dt = np.float32
+    xmn = np.tile(np.array([1.0, 2.0], dt), (N, 1)); xmx = np.tile(np.array([-1.0, -2.0], dt), (N, 1))          # x_min > x_max
+    umn = np.tile(np.array([2.0, 3.0], dt), (N - 1, 1)); umx = np.tile(np.array([-2.0, -3.0], dt), (N - 1, 1))  # u_min > u_max
+    B = 24
+    rng = np.random.default_rng(223)
+    x0 = rng.uniform(-1.5, 1.5, size=(B, nx)).astype(dt)
+    xref = (rng.standard_normal((B, N, nx)) * 0.3).astype(dt)
+    recs = []
+    st = O.new_state(B, nx, nu, N, dt)
+    st["x"][:, 0] = x0
+    for k, settings in enumerate((dict(O.DEFAULT_SETTINGS), dict(O.DEFAULT_SETTINGS, max_iter=7, abs_pri_tol=0.0, abs_dua_tol=0.0),
+                                  dict(O.DEFAULT_SETTINGS, check_termination=3, max_iter=40))):
+        pre = O.copy_state(st)
+        rc = O.Reference(prob, dt, settings).solve(st, xmn, xmx, umn, umx, xref)
+        recs.append(dict(k=k, pre=pre, post=O.copy_state(st), xref=xref.copy(), rc=int(rc), settings=settings))
+        st["y"][:] = 0; st["g"][:] = 0
+    save("codegen_random_f32_2_2_3", prob, dt, dict(O.DEFAULT_SETTINGS), recs,
+         dict(bnd_xmin=xmn, bnd_xmax=xmx, bnd_umin=umn, bnd_umax=umx))
+    print("  codegen_random iters", [r["post"]["iter"][:6].tolist() for r in recs])
+
+
 def closed_loop_traces():
     """Whole closed loops through the compiled reference; data only (inputs + per-step outputs)."""
     S = dict(O.DEFAULT_SETTINGS)
@@ -255,6 +291,11 @@ def closed_loop_traces():
     np.savez_compressed(OUT / "closed_loop_traces.npz", **d)
     print(f"wrote closed_loop_traces.npz ({(OUT / 'closed_loop_traces.npz').stat().st_size / 1024:.1f} KiB)")
 
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "codegen_random":
+    O.build(ref=True)
+    codegen_random_fixture()
+    sys.exit(0)
 
 if __name__ == "__main__":
     main()

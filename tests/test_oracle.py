@@ -25,6 +25,21 @@ def test_oracle_reproduces_golden_bit_exact(oracle_mod, name):
             assert np.array_equal(st[k], s["post"][k]), (name, s["k"], k, np.max(np.abs(st[k] - s["post"][k])))
 
 
+def test_oracle_reproduces_the_codegen_random_example(oracle_mod):
+    """examples/codegen_random.cpp:19-31 (n = 2, m = 2, N = 3, per-row bounds with min > max): golden vectors of the compiled
+    reference, bounds stored as full arrays."""
+    O = oracle_mod
+    meta, prob, solves, z = load_fixture("codegen_random_f32_2_2_3")
+    bnds = [z[k] for k in ("bnd_xmin", "bnd_xmax", "bnd_umin", "bnd_umax")]
+    assert (bnds[0] > bnds[1]).all() and (bnds[2] > bnds[3]).all()  # the example's infeasible boxes
+    for s in solves:
+        st = {k: v.copy() for k, v in s["pre"].items()}
+        rc = O.Oracle(prob, np.float32, s["settings"]).solve(st, *bnds, s["xref"])
+        assert (rc > 0) == (s["rc"] > 0)
+        for k in STATE_ORDER + ("residuals", "status", "iter"):
+            assert np.array_equal(st[k], s["post"][k]), (s["k"], k)
+
+
 def test_known_answers_of_the_survey(oracle_mod):
     """SURVEY.md §4 KATs of the unchanged reference, via the golden traces."""
     meta, prob, solves, z = load_fixture("quad_hover_f64_N10")
@@ -54,7 +69,8 @@ CFGS = [(np.float32, 12, 4, 30), (np.float64, 12, 4, 30), (np.float64, 12, 4, 10
         (np.float32, 4, 1, 10), (np.float64, 4, 1, 10), (np.float32, 8, 3, 7), (np.float32, 32, 16, 50),
         (np.float32, 8, 4, 9), (np.float32, 12, 2, 11), (np.float32, 4, 2, 8), (np.float32, 4, 4, 6), (np.float64, 8, 4, 9),
         (np.float32, 16, 8, 10), (np.float32, 16, 4, 10), (np.float32, 20, 8, 10), (np.float32, 24, 4, 10),
-        (np.float64, 12, 2, 11), (np.float64, 4, 2, 8), (np.float64, 4, 4, 6), (np.float64, 16, 4, 10)]
+        (np.float64, 12, 2, 11), (np.float64, 4, 2, 8), (np.float64, 4, 4, 6), (np.float64, 16, 4, 10),
+        (np.float32, 2, 2, 3), (np.float64, 2, 2, 3)]  # examples/codegen_random.cpp:19-21
 
 
 @pytest.mark.parametrize("dt,nx,nu,N", CFGS)

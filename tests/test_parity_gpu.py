@@ -838,7 +838,7 @@ def test_fp16_storage_vs_oracle(tinympc, oracle_mod, case, variant_name):
     settings = dict(O.DEFAULT_SETTINGS, max_iter=80)
     sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
     sol.select_kernel(VARIANTS[variant_name][0])
-    sol.set_storage(16)
+    sol.set_storage(16, 16)
     assert sol.kernel_name().endswith(",h16>"), sol.kernel_name()
     sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
     orc = O.Oracle(prob, "h16", settings)
@@ -968,7 +968,7 @@ def test_fp16_storage_step_functions(tinympc, oracle_mod):
     xref = O.round_h16(rng.standard_normal((B, N, nx)) * 0.3)
     settings = dict(O.DEFAULT_SETTINGS, check_termination=2, abs_pri_tol=0.5, abs_dua_tol=5.0)
     sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
-    sol.set_storage(16)
+    sol.set_storage(16, 16)
     sol.set_bounds(*bnds); sol.set_xref(xref)
     orc = O.Oracle(prob, "h16", settings)
     for fn in O.Oracle.STEP_FUNCTIONS:
@@ -996,7 +996,7 @@ def test_mixed_size_group_solve_fp16(tinympc, oracle_mod):
         bnds = pr.bounds_arrays(prob)
         settings = dict(O.DEFAULT_SETTINGS, max_iter=150)
         sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
-        sol.set_storage(16)
+        sol.set_storage(16, 16)
         sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
         st = O.new_state(B, nx, nu, N); st["x"][:, 0] = O.round_h16(x0)
         O.Oracle(prob, "h16", settings).solve(st, *[O.round_h16(b) for b in bnds], xref, nthreads=8)
@@ -1127,17 +1127,22 @@ def test_wave_kernel_fma_arithmetic(tinympc, oracle_mod, dims):
 @pytest.mark.parametrize("dims", [(20, 12, 12), (6, 2, 9), (30, 10, 7), (5, 5, 8), (3, 2, 6), (10, 3, 11), (40, 12, 6), (64, 32, 4), (33, 17, 5)])
 def test_classes_without_an_instantiation_run_on_the_padded_mfma_kernel(tinympc, oracle_mod, dims):
     """The reference takes any NSTATES / NINPUTS / NHORIZON (glob_opts.hpp:5-7).  A class with no compiled exact kernel is
-    served, in fma arithmetic, by the smallest MFMA streaming instantiation that contains it (any nx <= 64, nu <= 32, any N):
-    fixed-iteration results agree with the CPU restatement of the reference (plain sequential sums for these dimensions,
-    whose order the reference leaves to Eigen's alignment logic) to fp32 rounding, early exit converges the same instances."""
+    served, in fma arithmetic, by the smallest MFMA streaming instantiation that contains it (any nx <= 64, nu <= 32, any N).
+    Round 3: the yardstick is the COMPILED REFERENCE of exactly that class (oracle/Makefile FALLBACK_CONFIGS, fp32 and fp64
+    builds), not an unpinned restatement: at a fixed iteration count every array stays within 4x the reference's own
+    fp64-vs-fp32 spread (floor 2e-5 of the array's scale); with early exit the same instances converge, iteration counts
+    within the spread of the two reference builds + 2."""
     O, pr = oracle_mod, tinympc.problems
     nx, nu, N = dims
+    if not (O.have_ref(np.float32, nx, nu, N) and O.have_ref(np.float64, nx, nu, N)):
+        pytest.skip("oracle/_ref has no build of this class (needs /root/reference at build time)")
     prob = pr.random_system(nx, nu, N, seed=nx * 31 + nu)
     B = 53
     rng = np.random.default_rng(N)
     x0 = rng.uniform(-0.5, 0.5, size=(B, nx)).astype(np.float32)
     xref = (rng.standard_normal((B, N, nx)) * 0.1).astype(np.float32)
     bnds = pr.bounds_arrays(prob)
+    bnds64 = [np.asarray(b, np.float64) for b in bnds]
     for extra in (dict(max_iter=8, abs_pri_tol=0.0, abs_dua_tol=0.0), dict(max_iter=60)):
         settings = dict(O.DEFAULT_SETTINGS, **extra)
         sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
@@ -1146,17 +1151,22 @@ def test_classes_without_an_instantiation_run_on_the_padded_mfma_kernel(tinympc,
         sol.solve()
         got = sol.get_state()
         st = O.new_state(B, nx, nu, N); st["x"][:, 0] = x0
-        O.Oracle(prob, np.float32, settings, allow_unpinned_dims=True).solve(st, *bnds, xref, nthreads=8)
+        O.Reference(prob, np.float32, settings).solve(st, *bnds, xref)                       # the reference's fp32 build
+        s64 = O.new_state(B, nx, nu, N, np.float64); s64["x"][:, 0] = x0
+        O.Reference(prob, np.float64, settings).solve(s64, *bnds64, xref.astype(np.float64))  # ... and its fp64 build
         if extra["max_iter"] == 8:
             assert np.array_equal(got["iter"], st["iter"]) and np.array_equal(got["status"], st["status"])
-            for k in ("x", "u", "d", "p", "y", "g"):
+            for k in ("x", "u", "d", "p", "y", "g", "v", "z"):
                 scale = max(float(np.abs(st[k]).max()), 1e-2)
                 err = float(np.abs(got[k].astype(np.float64) - st[k]).max()) / scale
-                assert err <= 2e-4, f"{dims} {k}: {err:.2e}"
+                spread = float(np.abs(s64[k] - st[k]).max()) / scale
+                assert err <= max(4.0 * spread, 2e-5), f"{dims} {k}: GPU-vs-reference {err:.2e}, reference fp64-vs-fp32 {spread:.2e}"
         else:
             same = got["status"] == st["status"]
-            assert same.mean() >= 0.9, (dims, same.mean())
-            assert np.abs(got["iter"][same].astype(int) - st["iter"][same]).max() <= 6
+            same_ref = s64["status"] == st["status"]
+            assert same.mean() >= min(0.9, same_ref.mean()), (dims, same.mean(), same_ref.mean())
+            ref_iter_spread = int(np.abs(s64["iter"][same_ref].astype(int) - st["iter"][same_ref]).max()) if same_ref.any() else 0
+            assert np.abs(got["iter"][same].astype(int) - st["iter"][same]).max() <= ref_iter_spread + 2
         sol.close()
     with pytest.raises(tinympc.TinyBatchError):
         tinympc.TinyBatchSolver(pr.random_system(68, 4, 5, seed=1), 4)   # nx > 64: no kernel at all, refused at create
@@ -1333,7 +1343,7 @@ def test_kernel_selection_and_option_errors(tinympc):
     r = tinympc.TinyBatchSolver(pr.random_system(32, 16, 50), 4)    # wave-per-instance class
     assert r.kernel_name().startswith("waveres")
     with pytest.raises(tinympc.TinyBatchError):
-        r.set_storage(16)                                          # fp16 storage: row kernels only
+        r.set_storage(16, 16)                                          # fp16 storage: row kernels only
     with pytest.raises(tinympc.TinyBatchError):
         r.set_row_kernel(1)
     with pytest.raises(tinympc.TinyBatchError):
@@ -1364,7 +1374,7 @@ def test_per_instance_bounds_exact(tinympc, oracle_mod):
         settings = dict(O.DEFAULT_SETTINGS, max_iter=25, check_termination=2)
         for storage in ((32, 16) if name != "waveres" else (32,)):
             sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
-            sol.set_storage(storage)
+            sol.set_storage(storage, storage)
             sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
             want = "rowloop" if (storage == 16 and name == "rowlane") else name
             assert sol.kernel_name().startswith(want), sol.kernel_name()
@@ -1485,7 +1495,7 @@ def test_optional_terms_vs_oracle(tinympc, oracle_mod, case, exact):
         uref[..., 0, :] = 0.0
         sol = tinympc.TinyBatchSolver(prob, B, settings=base)
         sol.select_kernel(2 if exact else 3)
-        sol.set_storage(storage)
+        sol.set_storage(storage, storage)
         sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
         default_kernel = sol.kernel_name()
         sol.set_optional_terms(True, True)
@@ -1623,7 +1633,7 @@ def test_predicted_longest_first_dispatch(tinympc, oracle_mod, exact, family):
         for mode in (0, 1):
             sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
             sol.select_kernel(2 if exact else 3)
-            sol.set_storage(storage)
+            sol.set_storage(storage, storage)
             sol.set_row_kernel(family)
             sol.set_bounds(*pr.bounds_arrays(prob)); sol.set_xref_window(table, start); sol.set_x0(x0)
             assert sol.kernel_name().startswith("rowloop" if family == 2 else "rowlane")
@@ -1646,7 +1656,7 @@ def test_predicted_longest_first_dispatch(tinympc, oracle_mod, exact, family):
             for mode in (1, 0):
                 sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
                 sol.select_kernel(2 if exact else 3)
-                sol.set_storage(16)
+                sol.set_storage(16, 16)
                 sol.set_row_kernel(family)
                 sol.set_bounds(*pr.bounds_arrays(prob)); sol.set_xref_window(table, start); sol.set_x0(x0)
                 sol.set_dispatch(mode)
@@ -1943,7 +1953,13 @@ def test_config5_fp16_storage_against_the_fp32_reference(tinympc, oracle_mod, du
         ub = max(abs(prob["u_max"]), abs(prob["u_min"]))
         err = np.abs(got["u"][both, 0].astype(np.float64) - st["u"][both, 0]).max(axis=1) / ub
         drift = (got["iter"][both].astype(np.int64) - st["iter"][both])
+        # instances the fp16 run does NOT bring to the tolerance (they stop at max_iter): what a caller gets if it applies their
+        # u.col(0) anyway, against the fp32 reference's converged control (round 3: reported and bounded, not only the rest)
+        stalled = (got["status"] != 1) & (st["status"] == 1)
+        err_st = (np.abs(got["u"][stalled, 0].astype(np.float64) - st["u"][stalled, 0]).max(axis=1) / ub) if stalled.any() else np.zeros(1)
         report[name] = dict(conv_h16=float((got["status"] == 1).mean()), conv_f32=float((st["status"] == 1).mean()),
+                            u0_err_unconverged_max=float(err_st.max()), u0_err_unconverged_p99=float(np.percentile(err_st, 99)),
+                            frac_unconverged=float(stalled.mean()),
                             u0_err_max=float(err.max()), u0_err_p99=float(np.percentile(err, 99)), changed=float((drift != 0).mean()),
                             mean_drift=float(drift.mean()), mean_iter_h16=float(got["iter"].mean()), mean_iter_f32=float(st["iter"].mean()))
         sol.close()
@@ -1953,6 +1969,26 @@ def test_config5_fp16_storage_against_the_fp32_reference(tinympc, oracle_mod, du
         assert r["conv_h16"] >= conv_bar, (name, r)
         assert r["u0_err_max"] <= u_bar, (name, r)
         assert abs(r["mean_drift"]) <= drift_bar, (name, r)
+        # unconverged fp16 instances carry a u.col(0) that can be far off (measured r02: up to 0.67 of the input bound for the
+        # cartpole with 16-bit duals): the status flag, not the control, is what a caller must look at.  With fp32 duals the
+        # stalled quadrotor instances sit within an fp16 ulp of the answer (measured 1.4e-2 of the input bound; bounded here at 5 %);
+        # a stalled cartpole instance (1.7 % of the batch) can still be 0.7 of the bound off: reported, not bounded.
+        if dual_bits == 32 and name == "quadrotor":
+            assert r["u0_err_unconverged_max"] <= 5e-2, (name, r)
+
+
+def test_default_16_bit_storage_keeps_the_duals_in_fp32_where_a_register_resident_kernel_exists(tinympc):
+    """tiny_batch_set_storage(tb, 16) (no dual precision given): fp32 duals on the classes with an unrolled / quad kernel, 16-bit
+    duals where only the kernels that stream or roll their state exist; _ex(16, 16) forces binary16 everywhere."""
+    pr = tinympc.problems
+    for prob, want in ((pr.quadrotor(20, 30), ",h16d>"), (pr.cartpole(10), ",h16d>"), (pr.quadrotor(20, 17), ",h16>")):
+        sol = tinympc.TinyBatchSolver(prob, 64)
+        sol.set_storage(16)
+        sol.set_bounds(*pr.bounds_arrays(prob))
+        assert sol.kernel_name().endswith(want), sol.kernel_name()
+        sol.set_storage(16, 16)
+        assert sol.kernel_name().endswith(",h16>"), sol.kernel_name()
+        sol.close()
 
 
 def test_per_instance_bounds_stay_on_the_register_resident_kernel_and_cost_little(tinympc):
@@ -2263,3 +2299,24 @@ def test_group_gather_u0_from_python(tinympc):
     assert np.array_equal(out, want)
     for s in sols:
         s.close()
+
+
+def test_codegen_random_example_bitwise(tinympc, oracle_mod):
+    """The reference's own examples/codegen_random.cpp:19-31 — n = 2, m = 2, N = 3, rho = 0.1, per-row bounds with min > max — on
+    the exact kernels of the (2, 2) class (round 3: added to TINY_FOR_EACH_ROWDIMS): golden vectors of the compiled reference with
+    gains from the reference's tiny_codegen(), three chained solves, every array bit for bit, on the rolled-loop kernel (the
+    automatic choice), the streaming row kernel and the six single-function kernels' fused equivalent."""
+    meta, prob, solves, z = load_fixture("codegen_random_f32_2_2_3")
+    bnds = [z[k] for k in ("bnd_xmin", "bnd_xmax", "bnd_umin", "bnd_umax")]
+    for fam in (0, 2, 3):
+        for s in solves:
+            B = s["pre"]["x"].shape[0]
+            sol = tinympc.TinyBatchSolver(prob, B, settings=s["settings"])
+            sol.select_kernel(2); sol.set_row_kernel(fam)
+            sol.set_bounds(*bnds); sol.set_xref(s["xref"]); sol.set_state(s["pre"])
+            assert sol.kernel_name().startswith(("rowloop<2,2,exact", "rowstream<2,2,exact")), sol.kernel_name()
+            rc = sol.solve()
+            got = sol.get_state()
+            sol.close()
+            assert_bitwise(got, s["post"], f"codegen_random fam={fam} k={s['k']}")
+            assert rc == (1 if s["rc"] > 0 else 0)

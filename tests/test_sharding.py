@@ -93,8 +93,18 @@ def test_bench_two_rank_rehearsal(tmp_path):
         assert total == (8192 if config == "tracking" else 512) and d["config"]["instances_per_gpu"] == total // 2
         assert abs(d["value"] - total * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 1e-6
         assert d["config"]["frac_converged"] > 0.3 and "cpu_baseline" not in d
-    # a lone process asked for more GPUs than it is must refuse instead of measuring one
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    # round 3 (advisor): `python bench.py --gpus 2` without a launcher starts the two ranks itself (children spawned before torch or
+    # HIP is touched), forwards rank 0's line and the launcher's return code
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size_seen"] == 2 and d["config"]["instances_total"] == 8192
+    # inside an already launched group a mismatch is still refused instead of measuring the wrong number of GPUs
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1"], env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
 
 

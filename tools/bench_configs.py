@@ -86,21 +86,51 @@ def group(storage, variant, reps=5, dual_bits=None):
     out = []
     for sol in sols:
         it, stt, _ = sol.get_status()
-        out.append((sol.kernel_name(), it.copy(), float(np.mean(stt == 1)), sol.get_u()[:, 0].copy()))
+        out.append((sol.kernel_name(), it.copy(), float(np.mean(stt == 1)), sol.get_u()[:, 0].copy(), stt.copy()))
         sol.close()
     ms = float(np.median(ts))
     dnote = "" if dual_bits in (None, storage) else f" (duals fp{dual_bits})"
     print(f"cfg5 mixed 32768 cartpole + 32768 quadrotor, storage fp{storage}{dnote}, variant {variant}: {ms:7.3f} ms wall per group "
-          f"-> {65536 / ms * 1e3:.4g} solves/s; " + "; ".join(f"{k}: mean iters {i.mean():.2f}, converged {c:.3f}" for k, i, c, _ in out))
+          f"-> {65536 / ms * 1e3:.4g} solves/s; " + "; ".join(f"{k}: mean iters {i.mean():.2f}, converged {c:.3f}" for k, i, c, _, _ in out))
     return out
 
 
 for variant in (2, 3):
     ref = group(32, variant)
-    h16 = group(16, variant)
-    group(16, variant, dual_bits=32)
-    for (k32, i32, c32, u32), (k16, i16, c16, u16) in zip(ref, h16):
+    h16 = group(16, variant, dual_bits=16)
+    h16d = group(16, variant, dual_bits=32)
+    for (k32, i32, c32, u32, s32), (k16, i16, c16, u16, s16), (kd, idd, cd, ud, sd) in zip(ref, h16, h16d):
         same = i32 == i16
-        du = np.abs(u16[same] - u32[same]).max() / max(np.abs(u32).max(), 1e-6) if same.any() else float("nan")
+        scale = max(np.abs(u32).max(), 1e-6)
+        du = np.abs(u16[same] - u32[same]).max() / scale if same.any() else float("nan")
         print(f"   fp16-storage drift of {k16}: iteration count differs for {np.mean(~same):.3f} of the instances "
               f"(mean {i16.mean() - i32.mean():+.2f}); u0 of the others within {du:.2e} of the input scale")
+        for tag, u, st_ in (("16-bit duals", u16, s16), ("fp32 duals", ud, sd)):
+            bad = (st_ != 1) & (s32 == 1)
+            e = np.abs(u[bad] - u32[bad]).max() / scale if bad.any() else 0.0
+            print(f"   {tag}: {np.mean(bad):.3f} of the instances stop at max_iter (fp32 converges them); their u0 is off by up to {e:.2e} of the input scale")
+
+
+# ---- where fp16 storage pays: the state is STREAMED through L2/HBM every iteration (horizons beyond the register-resident kernels) ----
+def streamed(N, storage):
+    q = pr.quadrotor(20, N)
+    B = 65536
+    x0, table, start = pr.tracking_batch(B, N)
+    sol = T.TinyBatchSolver(q, B)
+    sol.select_kernel(2)
+    sol.set_storage(storage, storage)
+    sol.set_bounds(*pr.bounds_arrays(q)); sol.set_xref_window(table, start)
+    sol.enable_timing(True); ms = []
+    for r in range(4):
+        sol.reset_workspace(); sol.set_x0(x0); sol.solve_async(); sol.synchronize()
+        if r: ms.append(sol.last_solve_ms())
+    it, st, _ = sol.get_status()
+    print(f"quadrotor N={N} x{B}, {sol.kernel_name():30s} storage fp{storage}: {np.mean(ms):8.3f} ms  {B / np.mean(ms) * 1e3:10.4g} solves/s  "
+          f"mean iters {it.mean():.2f} converged {np.mean(st == 1):.3f}  workspace {6 * N * 16 * (storage // 8) * B / 1e6:.0f} MB "
+          f"({6 * N * 16 * (storage // 8)} B per instance: {288e9 / (6 * N * 16 * (storage // 8)) / 1e6:.1f} M instances per 288 GB)")
+    sol.close()
+
+
+for N in (80, 100):
+    for storage in (32, 16):
+        streamed(N, storage)
