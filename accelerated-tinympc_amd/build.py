@@ -28,7 +28,8 @@ HEADERS = [CSRC / "tinympc_internal.h", CSRC / "rowlane_math.h", CSRC / "tile_ma
 # which cannot read the accumulator half of the register file: left to its heuristics hipcc parks the products there and
 # copies every one of them back, 110 v_accvgpr_read per horizon step)
 EXTRA_FLAGS = {"admm_tile16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"] + os.environ.get("TINYMPC_T16_FLAGS", "").split(),
-               "admm_rowlane.hip": os.environ.get("TINYMPC_ROWLANE_FLAGS", "").split()}
+               "admm_rowlane.hip": os.environ.get("TINYMPC_ROWLANE_FLAGS", "").split(),
+               "admm_waveres.hip": os.environ.get("TINYMPC_WAVERES_FLAGS", "").split()}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-gpu-rdc"]
 
 

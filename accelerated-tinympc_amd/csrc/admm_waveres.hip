@@ -14,6 +14,9 @@
 // The bounds come from their table in global memory one step ahead (shared by the batch or per instance).
 // Two waves per SIMD (gains 96 + state 100 VGPRs), 13 KB of LDS per wave.
 #include "wave_math.h"
+#ifndef TINY_WAVERES_ABLATE_STORES
+#define TINY_WAVERES_ABLATE_STORES 0 // timing experiment only (results are wrong): no per-iteration write-through
+#endif
 
 namespace tinympc
 {
@@ -135,7 +138,9 @@ __global__ __launch_bounds__(WAVE, 2) void admm_waveres_kernel(const RowParams P
             pri = fmaxf(pri, fabsf(sv - t));                            // admm.cpp:95,97
             dua = fmaxf(dua, fabsf(b_cur - t));                         // admm.cpp:96,98
             b[i * WAVE] = t;
+#if !TINY_WAVERES_ABLATE_STORES
             P.vz[o] = b_cur; // v_i | z_i, should this iteration converge
+#endif
             t1 = t - an;
             const int inext = i + 1 < N ? i + 1 : i;
             lh = bnd[inext * WAVE];
@@ -176,7 +181,9 @@ __global__ __launch_bounds__(WAVE, 2) void admm_waveres_kernel(const RowParams P
             float pn, dd;
             const float lin = EXACT ? cq - rho * (sn_cur - ai) : __builtin_fmaf(-rho, sn_cur - ai, cq);
             wave_riccati_step<NX, NU, EXACT>(G, vec, lane, is_x, p, lin, pn, dd); // admm.cpp:19-20,80-82
+#if !TINY_WAVERES_ABLATE_STORES
             P.pd[o] = is_u ? dd : pn; // [p_i ; d_i] of this sweep (live-out only)
+#endif
             p = pn;
             sn_cur = b[(i > 0 ? i - 1 : 0) * WAVE];
             o -= WAVE;

@@ -122,3 +122,9 @@ for w in workloads:
     out["derived"] = d
     (prof / f"{tag}_{w}_counters.json").write_text(json.dumps(out, indent=1))
     print(w, json.dumps(d, indent=1))
+    # the table bench.py reads for roofline.traffic: "<kernel name>:<mode>:<batch>" -> HBM bytes per launch, bound to the kernel sources
+    if line and hbm.get("hbm_bytes_per_launch"):
+        tf = prof / "hbm_traffic.json"
+        table = json.loads(tf.read_text()) if tf.exists() else {}
+        table[f"{line['kernel']}:early_exit:{line['batch']}"] = {"bytes": hbm["hbm_bytes_per_launch"], "csrc_sha": out["csrc_sha"], "profile": f"{tag}_{w}_counters.json"}
+        tf.write_text(json.dumps(table, indent=1))
