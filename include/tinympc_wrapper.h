@@ -8,6 +8,10 @@
  *
  * What the reference bakes into the generated tiny_data_workspace.cpp at code-generation time (dimensions, cache,
  * dynamics, settings: codegen.cpp:322-470) is supplied once at run time through tiny_wrapper_setup().
+ * The four DATA symbols of the generated library are exported too — `settings`, `cache`, `work`, `tiny_data_solver`
+ * (codegen.cpp:470, :513), declared below with this repository's plain-array struct types (tinympc_admm.h) — and, as in the
+ * reference, the ten functions work on exactly that global solver: set_x0 writes work.x.col(0), call_tiny_solve runs
+ * tiny_solve(&tiny_data_solver), get_u copies work.u out.
  * Differences: functions are no-ops returning silently (like the reference, they return void) if setup has not been
  * called or a HIP error occurred — tiny_wrapper_last_status() reports it; `verbose != 0` prints a one-line summary
  * instead of every element.  Not re-entrant / not thread-safe, exactly like the reference's global tiny_data_solver.
@@ -27,6 +31,15 @@ extern "C"
     void tiny_wrapper_teardown(void);
     /* 0 if the last wrapper call succeeded, else the negative error code; *iter / *status = work->iter / work->status */
     int tiny_wrapper_last_status(int *iter, int *status);
+
+    /* the generated library's global solver (tiny_data_workspace.cpp emitted by codegen.cpp:322-470); members valid after
+     * tiny_wrapper_setup().  Declared here only when tinympc_admm.h (the struct types) has been included before. */
+#ifdef TINYMPC_ADMM_H
+    extern TinySettings settings;
+    extern TinyCache cache;
+    extern TinyWorkspace work;
+    extern TinySolver tiny_data_solver;
+#endif
 
     /* tiny_wrapper.hpp:14-23, identical names, argument meaning and flat orders (x0[i]; xref[j*NSTATES+i]; ...) */
     void set_x0(float *x0, int verbose);

@@ -156,6 +156,15 @@ def test_wrapper_library_exports_the_reference_wrapper_names(tinympc):
     # before setup every call is a reported no-op, never a crash
     lib.reset_dual_variables(0)
     assert lib.tiny_wrapper_last_status(None, None) < 0
+    # the generated library also exports four DATA symbols (codegen.cpp:470, :513; SURVEY.md section 8(b) `nm -D` row): a foreign
+    # caller that pokes tiny_data_solver links, and tiny_data_solver points at the other three
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", str(ROOT / "accelerated-tinympc_amd" / "lib" / "libtinympc_wrapper.so")], capture_output=True, text=True).stdout
+    data = {l.split()[-1]: l.split()[-2] for l in nm.splitlines() if len(l.split()) >= 3}
+    for sym in ("settings", "cache", "work", "tiny_data_solver"):
+        assert data.get(sym) in ("B", "D"), (sym, data.get(sym))   # bss / initialised data, not functions
+    ptrs = (C.c_void_p * 3).in_dll(lib, "tiny_data_solver")
+    assert [ptrs[0], ptrs[1], ptrs[2]] == [C.addressof(C.c_char.in_dll(lib, n)) for n in ("settings", "cache", "work")]
 
 
 def test_every_function_declared_in_the_wrapper_headers_is_exported(tinympc):
