@@ -313,16 +313,17 @@ __device__ __forceinline__ void masked_forward_update(unsigned long long m, floa
                                                       unsigned sn_addr, const f32x4 &t)
 {
     unsigned long long sx;
-    const f32x4 an = tp - t;
+    // the new dual a = tp - t (admm.cpp:69-70, (y + u) - znew) is computed here, under the narrowed EXEC, straight into its state
+    // registers: four subtractions instead of four subtractions plus four masked moves
     asm volatile("s_and_saveexec_b64 %[sx], %[m]\n\t"
-                 "v_mov_b32 %[a0], %[n0]\n\tv_mov_b32 %[a1], %[n1]\n\tv_mov_b32 %[a2], %[n2]\n\tv_mov_b32 %[a3], %[n3]\n\t"
+                 "v_sub_f32 %[a0], %[p0], %[t0]\n\tv_sub_f32 %[a1], %[p1], %[t1]\n\tv_sub_f32 %[a2], %[p2], %[t2]\n\tv_sub_f32 %[a3], %[p3], %[t3]\n\t"
                  "v_accvgpr_write_b32 %[b0], %[o0]\n\tv_accvgpr_write_b32 %[b1], %[o1]\n\tv_accvgpr_write_b32 %[b2], %[o2]\n\tv_accvgpr_write_b32 %[b3], %[o3]\n\t"
                  "ds_write_b128 %[ad], %[tv]\n\t"
                  "s_mov_b64 exec, %[sx]"
                  : [sx] "=&s"(sx), [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [b0] "+a"(bo[0]), [b1] "+a"(bo[1]),
                    [b2] "+a"(bo[2]), [b3] "+a"(bo[3])
-                 : [m] "s"(m), [n0] "v"(an[0]), [n1] "v"(an[1]), [n2] "v"(an[2]), [n3] "v"(an[3]), [o0] "v"(old[0]), [o1] "v"(old[1]),
-                   [o2] "v"(old[2]), [o3] "v"(old[3]), [ad] "v"(sn_addr), [tv] "v"(t)
+                 : [m] "s"(m), [p0] "v"(tp[0]), [p1] "v"(tp[1]), [p2] "v"(tp[2]), [p3] "v"(tp[3]), [t0] "v"(t[0]), [t1] "v"(t[1]), [t2] "v"(t[2]),
+                   [t3] "v"(t[3]), [o0] "v"(old[0]), [o1] "v"(old[1]), [o2] "v"(old[2]), [o3] "v"(old[3]), [ad] "v"(sn_addr), [tv] "v"(t)
                  : "memory", "scc"); // s_and_saveexec writes SCC
 }
 __device__ __forceinline__ void masked_backward_update(unsigned long long m, float (&pl)[3], float &dr, const float (&pn)[3], float dd)
@@ -354,24 +355,17 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
 {
     constexpr int NX = 12, NU = 4;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-    // dispatch order (round 3): wave w of workgroup b solves tile order[4b + w]; workgroups start in index order, so a list
-    // sorted by the predicted iteration count starts the long tiles first AND puts tiles of similar length on one CU
     const int ntiles = (P.batch + 15) >> 4;
-    const int slot = blockIdx.x * TILE16_WAVES + wv;
-    int tile = slot;
-    if (P.order) tile = slot < ntiles ? P.order[slot] : ntiles;
-    const bool tile_ok = tile >= 0 && tile < ntiles; // also rejects a bad entry of a caller-supplied order: such a wave stores nothing
-    const int inst = tile * 16 + c;
-    const bool valid = tile_ok && inst < P.batch;
-    const int inst_a = valid ? inst : P.batch - 1; // padding columns of the last tile load a valid instance and store nothing
     const float rho = P.rho;
     const f32x4 rho4 = {rho, rho, rho, rho};
 
     // ---- LDS (dynamic): per wave the slack [v|vnew ; z|znew] of every step (lane-linear float4), then the tables the four
     //      waves share: box bounds [step][g] -> registers v = 0..3 (row 4v + g), reference rows [row][g] -> x rows 4v + g
-    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
-    float4 *sn = lds4 + wv * (N * WAVE) + lane; // sn[i * WAVE]
-    float4 *blo = lds4 + TILE16_WAVES * N * WAVE, *bhi = blo + N * 4, *tab = bhi + N * 4;
+    extern __shared__ __attribute__((aligned(16))) float4 lds4_base[];
+    float4 *const lds4 = lds4_base;
+    float4 *const sn0 = lds4 + wv * (N * WAVE) + lane; // sn[i * WAVE]
+    float4 *const blo = lds4 + TILE16_WAVES * N * WAVE, *const bhi = blo + N * 4, *const tab0 = bhi + N * 4;
+    float4 *const tab = tab0;
     const int tab_rows = P.xref_mode == 1 ? P.table_rows : N;
     const float *tab_src = P.xref_mode == 1 ? P.xref_table : P.xref; // [rows][16]
     for (int e = threadIdx.x; e < N * 16; e += WAVE * TILE16_WAVES)
@@ -393,6 +387,30 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
 #pragma unroll
     for (int v = 0; v < 3; v++) qv[v] = P.mats[(2 * NX + 2 * NU) * 16 + 4 * v + g];
     qv[3] = 1.f;
+
+    // Persistent waves (round 3): the launch is one workgroup per CU and every wave draws tiles from a queue (an atomic counter
+    // behind RowParams::n_unsolved, zeroed by the host with it) until it is empty.  A CU's LDS belongs to its workgroup, so with
+    // one tile per wave the CU could not start new work before the slowest of its four tiles had ended; now a wave that finishes
+    // takes the next tile at once, and the tables above are staged once per CU instead of once per four tiles.  Tiles are taken
+    // in queue order = dispatch order: slot k is tile order[k] (longest predicted first) or tile k.
+    for (;;)
+    {
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(P.n_unsolved + 1, 1);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (slot >= ntiles) break; // every wave reaches this: the queue only grows
+    // (an opaque zero per tile in every LDS base address: they are invariant across tiles and hipcc would otherwise hoist the
+    // per-step addresses of prologue and epilogue out of the queue loop and spill them, as it would inside the iteration loop)
+    int ozt;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(ozt));
+    float4 *const sn = sn0 + ozt;
+    float4 *const lds4 = lds4_base + ozt;
+    int tile = slot;
+    if (P.order) tile = P.order[slot];
+    const bool tile_ok = tile >= 0 && tile < ntiles; // also rejects a bad entry of a caller-supplied order: such a wave stores nothing
+    const int inst = tile * 16 + c;
+    const bool valid = tile_ok && inst < P.batch;
+    const int inst_a = valid ? inst : P.batch - 1; // padding columns of the last tile load a valid instance and store nothing
 
     // ---- per-instance state, four words per horizon step (row 4v + g) ----
     //   a[i]   : g_i | y_i      duals                                                           (VGPR; four SEPARATE registers: as
@@ -598,7 +616,7 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
             P.iter[inst] = 1;
             atomicAdd(P.n_unsolved, 1);
         }
-        return;
+        continue;
     }
 
     // ---------------- live-out: every work array written once ----------------
@@ -694,6 +712,7 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
             if (!solved) atomicAdd(P.n_unsolved, 1);
         }
     }
+    } // tile queue
 }
 
 #define TINY_FOR_EACH_TILE16(X) X(30)
@@ -711,7 +730,9 @@ int tile16_max_table_rows() { return TILE16_MAX_TABLE_ROWS; }
 
 hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t stream)
 {
-    const int ntiles = (P.batch + 15) / 16, nblocks = (ntiles + TILE16_WAVES - 1) / TILE16_WAVES;
+    const int ntiles = (P.batch + 15) / 16;
+    static const int n_cu = []() { int dev = 0, n = 256; (void)hipGetDevice(&dev); hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; return n; }();
+    const int want = (ntiles + TILE16_WAVES - 1) / TILE16_WAVES, nblocks = want < n_cu ? want : n_cu; // one persistent workgroup per CU
     const int rows = P.xref_mode == 1 ? P.table_rows : N;
     if (rows > TILE16_MAX_TABLE_ROWS) return hipErrorInvalidValue;
     const size_t lds = (size_t)(TILE16_WAVES * N * WAVE + 2 * N * 4 + rows * 4) * sizeof(float4);

@@ -851,7 +851,7 @@ int run_step(TinyBatch *tb, int fn, int *converged_host, int *n_true)
     if (!tb->conv_dev) TRY(dev_alloc_zero((float **)&tb->conv_dev, tb->batch));
     RowParams P;
     fill_row_params(tb, P, tb->variant != VAR_ROW_FAST);
-    HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, sizeof(int), tb->stream));
+    HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, 2 * sizeof(int), tb->stream)); // [0] unsolved count, [1] tile queue of admm_tile16.hip
     hipError_t e = launch_admm_step(tb->nx, tb->nu, tb->variant != VAR_ROW_FAST, tb->h16, fn, P, tb->conv_dev, tb->stream);
     if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
     if (fn == STEP_TERMINATION_CONDITION)
@@ -910,7 +910,7 @@ constexpr int kDispatchMinGroups = 4096; // two rounds of waves on 256 CUs x 4 S
 int enqueue_solve(TinyBatch *tb, int v, bool record_events)
 {
     const int layout = (v == VAR_STREAM) ? LAYOUT_TILE : LAYOUT_ROW;
-    HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, sizeof(int), tb->stream));
+    HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, 2 * sizeof(int), tb->stream)); // [0] unsolved count, [1] tile queue of admm_tile16.hip
     // longest-first dispatch (dispatch_order.hip): predictor sweep + bucket sort ahead of the register-resident 16-lane kernels;
     // pays off only when the launch is several rounds of waves deep
     const int fam_l = layout == LAYOUT_ROW ? row_family(tb) : -1;
@@ -1066,7 +1066,7 @@ int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int dev
     if (int rc = dev_alloc_zero(&tb->res, (size_t)batch * 4)) return cleanup(rc);
     if (int rc = dev_alloc_zero((float **)&tb->status, batch)) return cleanup(rc);
     if (int rc = dev_alloc_zero((float **)&tb->iter, batch)) return cleanup(rc);
-    if (int rc = dev_alloc_zero((float **)&tb->n_unsolved, 1)) return cleanup(rc);
+    if (int rc = dev_alloc_zero((float **)&tb->n_unsolved, 2)) return cleanup(rc);
     if (int rc = dev_alloc_zero((float **)&tb->xref_start, batch)) return cleanup(rc);
     if (int rc = dev_alloc_zero(&tb->x0buf, (size_t)batch * nx)) return cleanup(rc);
     tb->staging_floats = (size_t)batch * N * (nx > nu ? nx : nu);
@@ -1580,7 +1580,7 @@ int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, 
         RowParams P;
         fill_row_params(tb, P, v == VAR_ROW_EXACT);
         P.mpc_steps = steps; P.window_advance = window_advance; P.u0_traj = d_u0_traj;
-        HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, sizeof(int), tb->stream));
+        HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, 2 * sizeof(int), tb->stream)); // [0] unsolved count, [1] tile queue of admm_tile16.hip
         hipError_t e = fam == 0 ? launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, false, P, tb->stream)
                                 : launch_admm_quadlane(tb->N, v == VAR_ROW_EXACT, false, P, tb->stream);
         if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
