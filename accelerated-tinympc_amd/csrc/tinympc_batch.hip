@@ -777,7 +777,9 @@ int row_family(const TinyBatch *tb)
     // auto (round 3): sixteen instances per wave on the matrix cores where the launch is at least two rounds deep for its one
     // wave per SIMD (2 048 tiles) — measured 1.79 against 1.91 ms on 65 536 tracking instances; smaller launches fill the chip
     // better with four instances per wave, and a closed-loop run keeps the kernel whose MPC loop stays on chip
-    if (tile16_applies(tb) && !tb->closed_loop_run && tb->batch >= kTile16AutoBatch) return 5;
+    // (a caller that hands over its own dispatch order lists groups of four instances: the automatic choice then stays with the
+    // kernel that order is for)
+    if (tile16_applies(tb) && !tb->closed_loop_run && !tb->order_dev && tb->batch >= kTile16AutoBatch) return 5;
     if (tb->row_dims_ok) return 0;
     if (tb->rowloop_ok) return 1;
     return 2;
@@ -1203,6 +1205,7 @@ int tiny_batch_set_dispatch_order_device(TinyBatch *tb, const int *d_order)
     CHECK_TB(tb);
     tb->order_dev = d_order;
     invalidate_graph(tb);
+    update_kname(tb); // a caller's order keeps the 16-lane kernel it is written for
     return 0;
 }
 
