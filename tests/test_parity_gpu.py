@@ -2320,3 +2320,30 @@ def test_codegen_random_example_bitwise(tinympc, oracle_mod):
             sol.close()
             assert_bitwise(got, s["post"], f"codegen_random fam={fam} k={s['k']}")
             assert rc == (1 if s["rc"] > 0 else 0)
+
+
+@pytest.mark.parametrize("exact,dispatch", [(True, 0), (True, 1), (False, 1)])
+def test_tile16_persistent_queue_at_full_size_equals_row_kernel_bitwise(tinympc, exact, dispatch):
+    """The headline kernel as the bench runs it (round 3): one persistent workgroup per CU, every wave drawing SEVERAL tiles from the
+    queue, tile-granular longest-first dispatch, a ragged last tile — against the 16-lane kernel on the same 40 037 tracking
+    instances: every work array, the residuals, status and the iteration counts of EVERY instance bit for bit, cold start and a
+    warm second solve (the instantiation that loads its live-in)."""
+    pr = tinympc.problems
+    prob = pr.quadrotor(20, 30)
+    B = 40037
+    x0, table, start = pr.tracking_batch(B, 30, seed=77)
+    res = {}
+    for fam in (5, 1):
+        sol = tinympc.TinyBatchSolver(prob, B)
+        sol.select_kernel(2 if exact else 3); sol.set_row_kernel(fam)
+        sol.set_bounds(*pr.bounds_arrays(prob)); sol.set_xref_window(table, start); sol.set_dispatch(dispatch)
+        assert sol.kernel_name().startswith("tile16<12,4,30" if fam == 5 else "rowlane<12,4,30"), sol.kernel_name()
+        sol.set_x0(x0); sol.solve()
+        assert sol.dispatch_applied() == dispatch
+        cold = sol.get_state()
+        sol.set_x0(x0 * np.float32(0.97)); sol.reset_dual_variables(); sol.solve()   # warm start from the first solve's workspace
+        res[fam] = (cold, sol.get_state())
+        sol.close()
+    for k, what in ((0, "cold"), (1, "warm")):
+        assert_bitwise(res[5][k], res[1][k], f"tile16 (persistent, dispatch {dispatch}) vs rowlane, exact={exact}, {what}, B={B}")
+    assert res[5][0]["iter"].max() >= 30 and res[5][0]["iter"].min() < 20  # the batch really is uneven: waves take different numbers of tiles
