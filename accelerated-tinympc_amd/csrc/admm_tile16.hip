@@ -725,7 +725,8 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
     } // tile queue
 }
 
-#define TINY_FOR_EACH_TILE16(X) X(30)
+// horizons: the slack of a wave is N KB of LDS, four waves and the shared tables must fit 160 KB: N <= 30
+#define TINY_FOR_EACH_TILE16(X) X(30) X(25) X(20) X(10)
 
 bool tile16_supported(int nx, int nu, int N)
 {

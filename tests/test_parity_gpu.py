@@ -2347,3 +2347,27 @@ def test_tile16_persistent_queue_at_full_size_equals_row_kernel_bitwise(tinympc,
     for k, what in ((0, "cold"), (1, "warm")):
         assert_bitwise(res[5][k], res[1][k], f"tile16 (persistent, dispatch {dispatch}) vs rowlane, exact={exact}, {what}, B={B}")
     assert res[5][0]["iter"].max() >= 30 and res[5][0]["iter"].min() < 20  # the batch really is uneven: waves take different numbers of tiles
+
+
+@pytest.mark.parametrize("N", [10, 20, 25])
+def test_tile16_other_horizons_equal_the_row_kernel_bitwise(tinympc, N):
+    """admm_tile16.hip is instantiated for the quadrotor horizons 10, 20, 25 and 30 (those whose slack fits its LDS share): each
+    against the unrolled 16-lane kernel of the same horizon, both arithmetic modes, ragged batch, cold and warm, bit for bit."""
+    pr = tinympc.problems
+    prob = pr.quadrotor(20, N)
+    B = 1000 + N
+    x0, table, start = pr.tracking_batch(B, N, seed=N)
+    for variant in (2, 3):
+        res = {}
+        for fam in (5, 1):
+            sol = tinympc.TinyBatchSolver(prob, B)
+            sol.select_kernel(variant); sol.set_row_kernel(fam)
+            sol.set_bounds(*pr.bounds_arrays(prob)); sol.set_xref_window(table, start)
+            assert sol.kernel_name().startswith(f"tile16<12,4,{N}" if fam == 5 else f"rowlane<12,4,{N}"), sol.kernel_name()
+            sol.set_x0(x0); sol.solve()
+            cold = sol.get_state()
+            sol.set_x0(x0 * np.float32(1.02)); sol.reset_dual_variables(); sol.solve()
+            res[fam] = (cold, sol.get_state())
+            sol.close()
+        for k in (0, 1):
+            assert_bitwise(res[5][k], res[1][k], f"tile16 vs rowlane, N={N}, variant {variant}, solve {k}")
