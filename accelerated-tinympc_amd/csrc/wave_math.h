@@ -119,6 +119,68 @@ struct WaveGains
     }
 };
 
+// ---- the same arithmetic cut at its broadcasts (round 3, admm_waveres.hip): a broadcast is "every lane stores its element, then every
+// lane reads the 16-byte groups it needs"; issued as early as its input exists and consumed as late as possible, independent work
+// of the step sits between the two halves instead of the wave waiting out the LDS round trip.
+template <int K0, int CNT>
+__device__ __forceinline__ void bcast_fetch(float (&v)[CNT], const float *vec)
+{
+    static_assert(K0 % 4 == 0 && CNT % 4 == 0, "whole 16-byte groups");
+#pragma unroll
+    for (int k4 = 0; k4 < CNT / 4; k4++)
+    {
+        const float4 q = reinterpret_cast<const float4 *>(vec + K0)[k4];
+        v[4 * k4 + 0] = q.x; v[4 * k4 + 1] = q.y; v[4 * k4 + 2] = q.z; v[4 * k4 + 3] = q.w;
+    }
+}
+template <int CNT>
+__device__ __forceinline__ void products_of(float (&t)[CNT], const float (&M)[CNT], const float (&v)[CNT])
+{
+#pragma unroll
+    for (int k = 0; k < CNT; k++) t[k] = M[k] * v[k];
+}
+// acc + sum_k M[k] * v[k] as four interleaved fma chains: exactly lane_fma_dot's arithmetic
+template <int CNT>
+__device__ __forceinline__ float fma_dot_of(float acc, const float (&M)[CNT], const float (&v)[CNT])
+{
+    static_assert(CNT % 4 == 0, "whole groups of four");
+    float a0 = acc, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int k4 = 0; k4 < CNT / 4; k4++)
+    {
+        a0 = __builtin_fmaf(M[4 * k4 + 0], v[4 * k4 + 0], a0); a1 = __builtin_fmaf(M[4 * k4 + 1], v[4 * k4 + 1], a1);
+        a2 = __builtin_fmaf(M[4 * k4 + 2], v[4 * k4 + 2], a2); a3 = __builtin_fmaf(M[4 * k4 + 3], v[4 * k4 + 3], a3);
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+// the gains of ONE sweep (same packing as WaveGains): loaded at the head of the sweep, so that the other sweep's 48 registers are free
+template <int NX, int NU>
+struct WaveGainsF
+{
+    float M1[NX], M2[NU];
+    __device__ __forceinline__ void load(const float *mats, int lane)
+    {
+        const float *m = mats + lane;
+#pragma unroll
+        for (int k = 0; k < NX; k++) M1[k] = m[(k) * WAVE];
+#pragma unroll
+        for (int k = 0; k < NU; k++) M2[k] = m[(NX + k) * WAVE];
+    }
+};
+template <int NX, int NU>
+struct WaveGainsB
+{
+    float M3[NX], M45[NU];
+    __device__ __forceinline__ void load(const float *mats, int lane)
+    {
+        const float *m = mats + lane;
+#pragma unroll
+        for (int k = 0; k < NX; k++) M3[k] = m[(NX + NU + k) * WAVE];
+#pragma unroll
+        for (int k = 0; k < NU; k++) M45[k] = m[(2 * NX + NU + k) * WAVE];
+    }
+};
+
 // forward_pass step (admm.cpp:31,35)
 template <int NX, int NU, bool EXACT = true>
 __device__ __forceinline__ void wave_lqr_step(const WaveGains<NX, NU> &G, float *vec, int lane, bool is_x, bool is_u, float s, float ci, float &sv, float &xn)
