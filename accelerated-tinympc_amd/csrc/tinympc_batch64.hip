@@ -351,10 +351,17 @@ __device__ __forceinline__ double lazy_sum(const double (&t)[CNT])
 #define TINY_FOR_EACH_F64ROWS(X) X(12, 4, 10) X(12, 4, 30) X(12, 4, 20) X(4, 1, 10) X(8, 4, 9)
 constexpr int F64_AHEAD = 4; // bounds are fetched this many steps ahead of their use
 
-template <int NX, int NU, int N>
+// RT = false: the horizon is the template parameter N.  RT = true ("any horizon", round 3): N is the CAPACITY of the unrolled body
+// (32 or 64 steps: registers are indexed statically, so the body stays unrolled) and the horizon n = P.N <= N is a launch parameter;
+// the steps past it are skipped by wave-uniform branches.  With a capacity of 64 the backward sweep's [p ; d] (live-out only) is
+// written through to its arrays instead of being held in 2 x 64 registers.
+template <int NX, int NU, int N, bool RT = false>
 __global__ __launch_bounds__(WAVE64, (N <= 12 ? 2 : 1)) void admm_f64_rows_kernel(const Params64 P, const double *__restrict__ gains)
 {
     static_assert(NX + NU <= 16 && !(NX >= 8 && NU >= 8), "16-lane mapping; both dims >= 8 would take Eigen's GEMV kernel");
+    static_assert(!RT || N > 20, "the runtime-horizon variant indexes the slack by the horizon: it keeps it in LDS");
+    const int n = RT ? P.N : N; // the horizon
+    constexpr bool PD_REG = !(RT && N > 32);
     const int lane = threadIdx.x, r16 = lane & 15;
     const int inst = blockIdx.x * 4 + (lane >> 4);
     const bool valid = inst < P.batch;
@@ -366,13 +373,13 @@ __global__ __launch_bounds__(WAVE64, (N <= 12 ? 2 : 1)) void admm_f64_rows_kerne
     // element (step, this lane's row) of the pair [x-type array ; u-type array]; u-type arrays have N - 1 steps
     auto ld = [&](int idx, int idu, int i) -> double {
         if (is_x) return P.arr[idx][((size_t)i * NX + row) * bp + b];
-        if (is_u && i < N - 1) return P.arr[idu][((size_t)i * NU + row) * bp + b];
+        if (is_u && i < n - 1) return P.arr[idu][((size_t)i * NU + row) * bp + b];
         return 0.0;
     };
     auto st = [&](int idx, int idu, int i, double v) {
         if (!valid) return;
         if (is_x) P.arr[idx][((size_t)i * NX + row) * bp + b] = v;
-        else if (is_u && i < N - 1) P.arr[idu][((size_t)i * NU + row) * bp + b] = v;
+        else if (is_u && i < n - 1) P.arr[idu][((size_t)i * NU + row) * bp + b] = v;
     };
     const bool en_b = is_x ? (P.en_state_bound != 0) : (is_u && P.en_input_bound != 0);
     // this lane's bounds of step i sit at pl0[i * bstep], ph0[i * bstep] (u rows have N - 1 steps; the other lanes read x row 0, unused)
@@ -402,7 +409,11 @@ __global__ __launch_bounds__(WAVE64, (N <= 12 ? 2 : 1)) void admm_f64_rows_kerne
     constexpr bool LDS_SLACK = N > 20;
     constexpr int NREG = LDS_SLACK ? 1 : N;
     __shared__ double slack_lds[LDS_SLACK ? 2 * N * WAVE64 : 1];
-    double a[N], c[N], pd[N], bb_r[NREG], sn_r[NREG];
+    // (two halves: hipcc leaves a statically indexed array of more than 32 doubles in scratch memory)
+    constexpr int NLO = N < 32 ? N : 32, NHI = N > 32 ? N - 32 : 1;
+    double a_lo[NLO], a_hi[NHI], c_lo[NLO], c_hi[NHI], pd[PD_REG ? N : 1], bb_r[NREG], sn_r[NREG];
+#define A_(i) ((i) < 32 ? a_lo[(i) < 32 ? (i) : 0] : a_hi[(i) < 32 ? 0 : (i) - 32])
+#define C_(i) ((i) < 32 ? c_lo[(i) < 32 ? (i) : 0] : c_hi[(i) < 32 ? 0 : (i) - 32])
     double *const sl = slack_lds + lane;
 #define BB_GET(i) (LDS_SLACK ? sl[(2 * (i)) * WAVE64] : bb_r[LDS_SLACK ? 0 : (i)])
 #define SN_GET(i) (LDS_SLACK ? sl[(2 * (i) + 1) * WAVE64] : sn_r[LDS_SLACK ? 0 : (i)])
@@ -412,14 +423,16 @@ __global__ __launch_bounds__(WAVE64, (N <= 12 ? 2 : 1)) void admm_f64_rows_kerne
 #pragma unroll
     for (int i = 0; i < N; i++)
     {
+        if (RT && i >= n) continue;
         double xr = 0.0;
         if (is_x) xr = P.xref[((size_t)i * NX + row) * (size_t)P.xref_stride + (P.xref_stride > 1 ? b : 0)];
-        pd[i] = ld(TINY_ARR_P, TINY_ARR_D, i);
-        c[i] = is_x ? -(xr * qrow) : pd[i];          // admm.cpp:81 | d_i
-        a[i] = ld(TINY_ARR_G, TINY_ARR_Y, i);
+        const double pdi = ld(TINY_ARR_P, TINY_ARR_D, i);
+        if constexpr (PD_REG) pd[i] = pdi;
+        C_(i) = is_x ? -(xr * qrow) : pdi;            // admm.cpp:81 | d_i
+        A_(i) = ld(TINY_ARR_G, TINY_ARR_Y, i);
         BB_SET(i, ld(TINY_ARR_V, TINY_ARR_Z, i));
         SN_SET(i, 0.0);
-        if (i == N - 1) xrN = xr;
+        if (i == n - 1) xrN = xr;
     }
     const double x0 = ld(TINY_ARR_X, TINY_ARR_U, 0); // x.col(0) on the x rows
     double pterm;
@@ -458,39 +471,40 @@ __global__ __launch_bounds__(WAVE64, (N <= 12 ? 2 : 1)) void admm_f64_rows_kerne
         asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
         const double *const pl = pl0 + oz, *const ph = ph0 + oz;
         auto ld_bounds = [&](int i, double &l, double &h) {
-            const size_t o = (size_t)((is_u && i >= N - 1) ? 0 : i) * bstep;
+            const size_t o = (size_t)((is_u && i >= n - 1) ? 0 : i) * bstep;
             l = pl[o]; h = ph[o];
         };
 #pragma unroll
-        for (int k = 0; k < F64_AHEAD; k++) ld_bounds(k < N ? k : N - 1, lo[k], hi[k]);
+        for (int k = 0; k < F64_AHEAD; k++) ld_bounds(k < n ? k : n - 1, lo[k], hi[k]);
 #pragma unroll
         for (int i = 0; i < N; i++)
         {
+            if (RT && i >= n) continue;
             double sv, xn = 0.0;
-            if (i < N - 1)
+            if (i < n - 1)
             {
                 double t[NX], t2[NU];
                 row_products<0, NX>(t, s, M1);
                 const double acc = is_x ? lazy_sum<NX>(t) : lazy_sum<NU>(t);   // Adyn*x | Kinf*x
-                const double un = -acc - c[i];                                   // admm.cpp:31
+                const double un = -acc - C_(i);                                   // admm.cpp:31
                 row_products<NX, NU>(t2, un, M2);
                 xn = acc + lazy_sum<NX>(t2);                                     // admm.cpp:35
                 sv = is_u ? un : s;
             }
             else sv = is_x ? s : 0.0;
             const double lo_i = lo[i % F64_AHEAD], hi_i = hi[i % F64_AHEAD];
-            if (i + F64_AHEAD < N) ld_bounds(i + F64_AHEAD, lo[i % F64_AHEAD], hi[i % F64_AHEAD]);
-            const double t0 = sv + a[i];                                         // admm.cpp:47-48
+            if (i + F64_AHEAD < n) ld_bounds(i + F64_AHEAD, lo[i % F64_AHEAD], hi[i % F64_AHEAD]);
+            const double t0 = sv + A_(i);                                         // admm.cpp:47-48
             double tc = t0;
-            if (en_b && (i < N - 1 || is_x))                                     // admm.cpp:51-60: min(max, max(min, t)); u has N - 1 steps
+            if (en_b && (i < n - 1 || is_x))                                     // admm.cpp:51-60: min(max, max(min, t)); u has N - 1 steps
             {
                 tc = (lo_i < tc) ? tc : lo_i;
                 tc = (tc < hi_i) ? tc : hi_i;
             }
-            const double an = (a[i] + sv) - tc;                                  // admm.cpp:69-70
+            const double an = (A_(i) + sv) - tc;                                  // admm.cpp:69-70
             pri = fmax(pri, fabs(sv - tc));                                      // admm.cpp:95,97
             dua = fmax(dua, fabs(BB_GET(i) - tc));                               // admm.cpp:96,98
-            a[i] = active ? an : a[i];
+            A_(i) = active ? an : A_(i);
             if constexpr (LDS_SLACK) { if (active) SN_SET(i, tc); }
             else sn_r[LDS_SLACK ? 0 : i] = active ? tc : sn_r[LDS_SLACK ? 0 : i];
             t1 = tc - an;
@@ -510,16 +524,17 @@ __global__ __launch_bounds__(WAVE64, (N <= 12 ? 2 : 1)) void admm_f64_rows_kerne
         if (!__any(active)) break;
         // ---- v = vnew, z = znew (admm.cpp:141-142), update_linear_cost + backward_pass_grad (admm.cpp:15-22, 80-82) ----
         double p = pN;
-        if constexpr (LDS_SLACK) { if (active) BB_SET(N - 1, SN_GET(N - 1)); }
+        if constexpr (LDS_SLACK) { if (active) BB_SET(n - 1, SN_GET(n - 1)); }
         else bb_r[LDS_SLACK ? 0 : N - 1] = active ? sn_r[LDS_SLACK ? 0 : N - 1] : bb_r[LDS_SLACK ? 0 : N - 1];
 #pragma unroll
         for (int i = N - 2; i >= 0; i--)
         {
+            if (RT && i > n - 2) continue;
             const double sni = SN_GET(i);
             if constexpr (LDS_SLACK) { if (active) BB_SET(i, sni); }
             else bb_r[LDS_SLACK ? 0 : i] = active ? sni : bb_r[LDS_SLACK ? 0 : i];
-            const double cq = is_x ? c[i] : -0.0; // u rows: r = -rho*(znew - y) keeps the sign of a zero difference
-            const double lin = cq - rho * (sni - a[i]);
+            const double cq = is_x ? C_(i) : -0.0; // u rows: r = -rho*(znew - y) keeps the sign of a zero difference
+            const double lin = cq - rho * (sni - A_(i));
             double t[NX], tk[NU], td[NU];
             row_products<0, NX>(t, p, M3);
             // x rows: AmBKt*p (coefficient-evaluated: halving tree, or sequential when nu = 1); u rows: Bdyn^T*p (vectorised reduction)
@@ -529,8 +544,9 @@ __global__ __launch_bounds__(WAVE64, (N <= 12 ? 2 : 1)) void admm_f64_rows_kerne
             row_products<NX, NU>(td, wv, M45);         // Quu_inv * (Bdyn^T p + r)
             const double pn = wv - vec_sum(tk);        // admm.cpp:20
             const double dd = lazy_sum<NU>(td);        // admm.cpp:19
-            pd[i] = active ? (is_u ? dd : pn) : pd[i];
-            c[i] = (active && is_u && !keep_d) ? dd : c[i];
+            if constexpr (PD_REG) pd[i] = active ? (is_u ? dd : pn) : pd[i];
+            else { if (active) st(TINY_ARR_P, TINY_ARR_D, i, is_u ? dd : pn); }
+            C_(i) = (active && is_u && !keep_d) ? dd : C_(i);
             p = pn;
         }
     }
@@ -541,13 +557,14 @@ __global__ __launch_bounds__(WAVE64, (N <= 12 ? 2 : 1)) void admm_f64_rows_kerne
 #pragma unroll
         for (int i = 0; i < N; i++)
         {
+            if (RT && i >= n) continue;
             double sv, xn = 0.0;
-            if (i < N - 1) // x, u regenerated from the d of the last executed forward sweep by the same instruction sequence
+            if (i < n - 1) // x, u regenerated from the d of the last executed forward sweep by the same instruction sequence
             {
                 double t[NX], t2[NU];
                 row_products<0, NX>(t, s, M1);
                 const double acc = is_x ? lazy_sum<NX>(t) : lazy_sum<NU>(t);
-                const double un = -acc - c[i];
+                const double un = -acc - C_(i);
                 row_products<NX, NU>(t2, un, M2);
                 xn = acc + lazy_sum<NX>(t2);
                 sv = is_u ? un : s;
@@ -556,11 +573,12 @@ __global__ __launch_bounds__(WAVE64, (N <= 12 ? 2 : 1)) void admm_f64_rows_kerne
             s = xn;
             st(TINY_ARR_X, TINY_ARR_U, i, sv);
             const double sni = SN_GET(i);
-            st(TINY_ARR_Q, TINY_ARR_R, i, (is_x ? c[i] : -0.0) - rho * (sni - a[i]));
-            st(TINY_ARR_P, TINY_ARR_D, i, i == N - 1 ? pN : pd[i]);
+            st(TINY_ARR_Q, TINY_ARR_R, i, (is_x ? C_(i) : -0.0) - rho * (sni - A_(i)));
+            if constexpr (PD_REG) st(TINY_ARR_P, TINY_ARR_D, i, i == n - 1 ? pN : pd[i]);
+            else { if (i == n - 1) st(TINY_ARR_P, TINY_ARR_D, i, pN); }
             st(TINY_ARR_V, TINY_ARR_Z, i, BB_GET(i));
             st(TINY_ARR_VNEW, TINY_ARR_ZNEW, i, sni);
-            st(TINY_ARR_G, TINY_ARR_Y, i, a[i]);
+            st(TINY_ARR_G, TINY_ARR_Y, i, A_(i));
         }
         if (valid && r16 == 0)
         {
@@ -570,6 +588,8 @@ __global__ __launch_bounds__(WAVE64, (N <= 12 ? 2 : 1)) void admm_f64_rows_kerne
             if (!solved) atomicAdd(P.n_unsolved, 1);
         }
     }
+#undef A_
+#undef C_
 #undef BB_GET
 #undef SN_GET
 #undef BB_SET
@@ -869,11 +889,22 @@ size_t mat_off(const TinyBatch64 *tb, int which) // Kinf, Pinf, Quu_inv, AmBKt, 
     for (int k = 0; k < which; k++) o += sz[k];
     return o;
 }
-bool rows_supported(int nx, int nu, int N)
+// classes of the sixteen-lane kernel with a runtime horizon (any N <= 64): the unrolled body has a capacity of 32 or 64 steps
+#define TINY_FOR_EACH_F64ROWS_RT(X) X(12, 4) X(4, 1) X(8, 4) X(12, 2) X(4, 2) X(4, 4)
+constexpr int F64ROWS_RT_MAX_N = 64;
+bool rows_unrolled(int nx, int nu, int N)
 {
 #define TINY_F64ROWS_CHECK(NX, NU, NN) \
     if (nx == NX && nu == NU && N == NN) return true;
     TINY_FOR_EACH_F64ROWS(TINY_F64ROWS_CHECK)
+    return false;
+}
+bool rows_supported(int nx, int nu, int N)
+{
+    if (rows_unrolled(nx, nu, N)) return true;
+#define TINY_F64ROWS_RT_CHECK(NX, NU) \
+    if (nx == NX && nu == NU && N >= 2 && N <= F64ROWS_RT_MAX_N) return true;
+    TINY_FOR_EACH_F64ROWS_RT(TINY_F64ROWS_RT_CHECK)
     return false;
 }
 // lane r of a row holds, per matrix column, the element of the row it owns (x rows r < nx, u rows nx <= r < nx + nu):
@@ -1126,7 +1157,17 @@ int tiny_batch64_solve(TinyBatch64 *tb)
 #define TINY_F64ROWS_LAUNCH(NX, NU, NN)                                                                                            \
     if (tb->nx == NX && tb->nu == NU && tb->N == NN)                                                                               \
         hipLaunchKernelGGL((admm_f64_rows_kernel<NX, NU, NN>), dim3(nrow_blocks), dim3(WAVE64), 0, 0, P, (const double *)tb->row_gains);
-        TINY_FOR_EACH_F64ROWS(TINY_F64ROWS_LAUNCH)
+        if (rows_unrolled(tb->nx, tb->nu, tb->N)) { TINY_FOR_EACH_F64ROWS(TINY_F64ROWS_LAUNCH) }
+        else
+        {
+#define TINY_F64ROWS_RT_LAUNCH(NX, NU)                                                                                              \
+    if (tb->nx == NX && tb->nu == NU)                                                                                               \
+    {                                                                                                                               \
+        if (tb->N <= 32) hipLaunchKernelGGL((admm_f64_rows_kernel<NX, NU, 32, true>), dim3(nrow_blocks), dim3(WAVE64), 0, 0, P, (const double *)tb->row_gains); \
+        else hipLaunchKernelGGL((admm_f64_rows_kernel<NX, NU, 64, true>), dim3(nrow_blocks), dim3(WAVE64), 0, 0, P, (const double *)tb->row_gains);             \
+    }
+            TINY_FOR_EACH_F64ROWS_RT(TINY_F64ROWS_RT_LAUNCH)
+        }
     }
     else
     {
@@ -1188,7 +1229,8 @@ const char *tiny_batch64_kernel_name(TinyBatch64 *tb)
     static thread_local char nm[64];
     if (!tb) return "";
     const bool rows = tb->kernel_choice == 2 || (tb->kernel_choice == 0 && rows_supported(tb->nx, tb->nu, tb->N));
-    if (rows) snprintf(nm, sizeof nm, "rows64<%d,%d,%d>", tb->nx, tb->nu, tb->N);
+    if (rows && !rows_unrolled(tb->nx, tb->nu, tb->N)) snprintf(nm, sizeof nm, "rows64<%d,%d,n<=%d>", tb->nx, tb->nu, tb->N <= 32 ? 32 : 64);
+    else if (rows) snprintf(nm, sizeof nm, "rows64<%d,%d,%d>", tb->nx, tb->nu, tb->N);
     else snprintf(nm, sizeof nm, "thread64<%d,%d>", tb->nx, tb->nu);
     return nm;
 }

@@ -15,8 +15,8 @@
  *
  * Scope: tiny_solve, the six step functions, a closed-loop step and the wrapper-style accessors.  Problem classes with a compiled
  * instantiation: (nx, nu) = (12, 4), (4, 1), (8, 4), (12, 2), (4, 2), (4, 4), (16, 4), any horizon N (TINY_FOR_EACH_F64DIMS).
- * Two kernels with identical results: sixteen lanes per instance with the state in registers for the whole solve (instantiated horizons, the default where one exists) and one thread per instance with the
- * state in HBM (any N).
+ * Two kernels with identical results: sixteen lanes per instance with the state on chip for the whole solve (nx + nu <= 16 and N <= 64: unrolled instantiations for the
+ * reference's horizons, a launch-parameter horizon otherwise; the default where it applies) and one thread per instance with the state in HBM (any N).
  */
 #ifndef TINYMPC_BATCH64_H
 #define TINYMPC_BATCH64_H

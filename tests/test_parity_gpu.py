@@ -2196,10 +2196,21 @@ def test_fp64_device_closed_loop_vs_oracle(tinympc, oracle_mod, nx, nu, N):
 
 
 F64_ROWS = {(12, 4, 10), (12, 4, 30), (12, 4, 20), (4, 1, 10), (8, 4, 9)}   # TINY_FOR_EACH_F64ROWS
+F64_ROWS_RT = {(12, 4), (4, 1), (8, 4), (12, 2), (4, 2), (4, 4)}            # TINY_FOR_EACH_F64ROWS_RT: any horizon up to 64
+
+
+def f64_rows_name(nx, nu, N):
+    """Name of the sixteen-lane fp64 kernel that serves (nx, nu, N), or None."""
+    if (nx, nu, N) in F64_ROWS:
+        return f"rows64<{nx},{nu},{N}>"
+    if (nx, nu) in F64_ROWS_RT and 2 <= N <= 64:
+        return f"rows64<{nx},{nu},n<={32 if N <= 32 else 64}>"
+    return None
 
 
 @pytest.mark.parametrize("kernel", [1, 2])
-@pytest.mark.parametrize("nx,nu,N", [(12, 4, 30), (12, 4, 10), (12, 4, 20), (4, 1, 10), (8, 4, 9), (12, 4, 13), (12, 2, 11), (4, 2, 8), (4, 4, 6), (16, 4, 10)])
+@pytest.mark.parametrize("nx,nu,N", [(12, 4, 30), (12, 4, 10), (12, 4, 20), (4, 1, 10), (8, 4, 9), (12, 4, 13), (12, 2, 11), (4, 2, 8), (4, 4, 6), (16, 4, 10),
+                                     (12, 4, 2), (12, 4, 32), (12, 4, 33), (12, 4, 64), (4, 1, 47), (8, 4, 40), (12, 4, 65)])
 def test_fp64_vs_oracle(tinympc, oracle_mod, nx, nu, N, kernel):
     """The fp64 library against the fp64 oracle (== the compiled reference's fp64 builds, tests/test_oracle.py) on random
     warm states with zeros and negative zeros: ragged batches, warm-started chain with dual resets, sparse termination
@@ -2230,12 +2241,15 @@ def test_fp64_vs_oracle(tinympc, oracle_mod, nx, nu, N, kernel):
         else:
             bnds, xref = shared, rng.standard_normal((N, nx)) * 0.2
         sol = tinympc.TinyBatchSolver64(prob, B, settings=settings)
-        if kernel == 2 and (nx, nu, N) not in F64_ROWS:   # no sixteen-lane instantiation for this class / horizon: refused, the thread kernel serves it
+        rows_name = f64_rows_name(nx, nu, N)
+        assert sol.kernel_name() == (rows_name or f"thread64<{nx},{nu}>")   # the automatic choice
+        if kernel == 2 and rows_name is None:   # no sixteen-lane kernel for this class / horizon: refused, the thread kernel serves it
             with pytest.raises(tinympc.TinyBatchError):
                 sol.select_kernel(2)
             assert sol.kernel_name() == f"thread64<{nx},{nu}>"
         else:
             sol.select_kernel(kernel)
+            assert sol.kernel_name() == (rows_name if kernel == 2 else f"thread64<{nx},{nu}>")
         sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_state(st)
         orc = O.Oracle(prob, np.float64, settings)
         for k in range(3):
