@@ -12,11 +12,20 @@
 //   * what leaves the chip per iteration is write-only and off the dependent chain: the replaced slack (the live-out v | z
 //     should this iteration converge, admm.cpp:135-142) and [p ; d] of the backward sweep (live-out only), 512 B per step.
 // The bounds come from their table in global memory one step ahead (shared by the batch or per instance).
-// Two waves per SIMD (gains 96 + state 100 VGPRs), 13 KB of LDS per wave.
+// Two waves per SIMD, 13 KB of LDS per wave.
+//
+// Round 3: the sweeps are software pipelined around their LDS broadcasts.  Counters had shown a wave parked
+// in s_waitcnt for 27 % of its life — two (forward) and three (backward) broadcast round trips per horizon step, each waited out in
+// place — and the vector pipe of a SIMD 58 % busy.  Now
+//   * a broadcast is issued (store + 16-byte reads) as soon as its input exists and consumed as late as possible: in the forward step
+//     the slack / dual arithmetic of the step sits behind the issue of the u broadcast and the residual maxima behind that of x_{i+1};
+//     in the backward step the broadcast of p_i is issued first, then the linear cost of step i - 1 with ITS broadcast and
+//     Kinf^T r_{i-1} (none of which depends on p), then Quu_inv (Bdyn^T p + r) of step i — three broadcasts in flight together and only
+//     the products of the next step wait for the first;
+//   * the gains of a sweep are loaded at its head (48 registers, L1/L2 resident, once per 49 steps) instead of holding both sweeps'
+//     96 for the whole solve: that is what makes room for the values in flight (and removes the scratch spills).
+// The arithmetic and its order are untouched (wave_math.h), results stay bitwise.
 #include "wave_math.h"
-#ifndef TINY_WAVERES_ABLATE_STORES
-#define TINY_WAVERES_ABLATE_STORES 0 // timing experiment only (results are wrong): no per-iteration write-through
-#endif
 
 namespace tinympc
 {
@@ -39,17 +48,18 @@ __global__ __launch_bounds__(WAVE, 2) void admm_waveres_kernel(const RowParams P
 {
     using PL = WavePlans<NX, NU>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *vec = lds;                 // [64] broadcast buffer of lane_products
+    float *const vec = lds;               // [64] x_i | u_i broadcast of the forward sweep (and of the terminal term)
+    float *const vecP = lds + WAVE;       // [64] p broadcast of the backward sweep
+    float *const vecL = lds + 2 * WAVE;   // [64] linear cost [q ; r] broadcast
+    float *const vecW = lds + 3 * WAVE;   // [64] q + AmBKt p | Bdyn^T p + r broadcast
     const int lane = threadIdx.x;
-    float *b = lds + WAVE + lane;     // b[i * WAVE]: slack of step i, in place
+    float *b = lds + 4 * WAVE + lane;     // b[i * WAVE]: slack of step i, in place
     const int inst = blockIdx.x;
     const bool is_x = lane < NX, is_u = (lane >= NX) && (lane < NX + NU);
     const int N = P.N;
     const int rowbase = (inst * N) * WAVE + lane;
     const float rho = P.rho;
     const float2 *bnd = reinterpret_cast<const float2 *>(P.bounds) + (size_t)inst * P.bounds_inst_stride + lane; // bnd[i * WAVE]
-    WaveGains<NX, NU> G;
-    G.load(P.mats, lane);
     const float qrow = P.mats[(2 * NX + 2 * NU) * WAVE + lane];
     int wstart = 0;
     if (P.xref_mode == 1) wstart = P.xref_start[inst];
@@ -122,39 +132,80 @@ __global__ __launch_bounds__(WAVE, 2) void admm_waveres_kernel(const RowParams P
         // the last permitted iteration must not overwrite d in c: x,u of an instance that exhausts max_iter come from the d
         // its last forward sweep used (regenerated in the epilogue); the final d itself is in the pd array
         const bool keep_d = (it == P.max_iter - 1);
+        float t1 = 0.f;
+        float pri = 0.f, dua = 0.f;
         // ---------------- forward sweep: forward_pass + update_slack + update_dual + residual maxima ----------------
-        float s = x0, pri = 0.f, dua = 0.f, t1 = 0.f;
-        float2 lh = bnd[0];
-        float b_cur = b[0];
-        int o = rowbase;
-        // one horizon step: ai/ci = this step's dual and feed-forward; returns the new dual
-        auto fwd_step = [&](int i, float ai, float ci) {
-            float sv, xn = 0.f;
-            if (i < N - 1) wave_lqr_step<NX, NU, EXACT>(G, vec, lane, is_x, is_u, s, ci, sv, xn);
-            else sv = is_x ? s : 0.f;
-            const float t0 = sv + ai;                                   // admm.cpp:47-48 and the sum of :69-70
-            const float t = __builtin_amdgcn_fmed3f(t0, lh.x, lh.y);    // admm.cpp:51-60 (lo := min(lo, hi) on the host)
-            const float an = t0 - t;                                    // admm.cpp:69-70  (a + sv) - t
-            pri = fmaxf(pri, fabsf(sv - t));                            // admm.cpp:95,97
-            dua = fmaxf(dua, fabsf(b_cur - t));                         // admm.cpp:96,98
-            b[i * WAVE] = t;
-#if !TINY_WAVERES_ABLATE_STORES
-            P.vz[o] = b_cur; // v_i | z_i, should this iteration converge
-#endif
-            t1 = t - an;
-            const int inext = i + 1 < N ? i + 1 : i;
-            lh = bnd[inext * WAVE];
-            b_cur = b[inext * WAVE];
-            o += WAVE;
-            s = xn;
-            return an;
-        };
+        {
+            WaveGainsF<NX, NU> GF;
+            int oz; // an opaque zero: the loads are loop invariant, and hoisted out of the iteration loop they would be live across both sweeps again
+            asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+            GF.load(P.mats + oz, lane);
+            float s = x0;
+            float2 lh = bnd[0];
+            float b_cur = b[0];
+            int o = rowbase;
+            float xv[NX]; // x_i as every lane sees it
+            vec[lane] = s;
+            bcast_fetch<0, NX>(xv, vec);
+            auto fwd_step = [&](int i, float ai, float ci) {
+                float sv, xn = 0.f, acc = 0.f;
+                float uv[NU];
+                if (i < N - 1) // u_i = -Kinf x_i - d_i (admm.cpp:31): products of the broadcast x_i, summed in the reference's order
+                {
+                    float un;
+                    if constexpr (EXACT)
+                    {
+                        float t[NX];
+                        products_of(t, GF.M1, xv);
+                        if constexpr (PL::FWD_U == PL::FWD_XA) acc = wreduce<PL::FWD_XA>(t);
+                        else acc = is_x ? wreduce<PL::FWD_XA>(t) : wreduce<PL::FWD_U>(t);
+                        un = -acc - ci; // u rows of M1 hold +Kinf: -(K x) - d with the sum negated, like the reference
+                    }
+                    else
+                    {
+                        acc = fma_dot_of(0.f, GF.M1, xv); // u rows of M1 hold -Kinf (pack_gains, fast)
+                        un = acc - ci;
+                    }
+                    vec[lane] = un;               // broadcast of u_i: issued here ...
+                    bcast_fetch<NX, NU>(uv, vec);
+                    sv = is_u ? un : s;
+                }
+                else sv = is_x ? s : 0.f;
+                // ... and the slack / dual update of the step runs while it is in flight
+                const float t0 = sv + ai;                                   // admm.cpp:47-48 and the sum of :69-70
+                const float t = __builtin_amdgcn_fmed3f(t0, lh.x, lh.y);    // admm.cpp:51-60 (lo := min(lo, hi) on the host)
+                const float an = t0 - t;                                    // admm.cpp:69-70  (a + sv) - t
+                b[i * WAVE] = t;
+                if (i < N - 1) // x_{i+1} = Adyn x_i + Bdyn u_i (admm.cpp:35)
+                {
+                    if constexpr (EXACT)
+                    {
+                        float t2[NU];
+                        products_of(t2, GF.M2, uv);
+                        xn = acc + wreduce<PL::FWD_XB>(t2);
+                    }
+                    else xn = fma_dot_of(acc, GF.M2, uv);
+                    vec[lane] = xn;               // broadcast of x_{i+1}: consumed by the next step,
+                    bcast_fetch<0, NX>(xv, vec);
+                }
+                pri = fmaxf(pri, fabsf(sv - t));                            // ... behind the residual maxima (admm.cpp:95-98)
+                dua = fmaxf(dua, fabsf(b_cur - t));
+                P.vz[o] = b_cur; // v_i | z_i, should this iteration converge
+                t1 = t - an;
+                const int inext = i + 1 < N ? i + 1 : i;
+                lh = bnd[inext * WAVE];
+                b_cur = b[inext * WAVE];
+                o += WAVE;
+                s = xn;
+                return an;
+            };
 #pragma unroll 1
-        for (int i = 0; i < (N < 32 ? N : 32); i++) a.lo[i] = fwd_step(i, a.lo[i], c.lo[i]);
+            for (int i = 0; i < (N < 32 ? N : 32); i++) a.lo[i] = fwd_step(i, a.lo[i], c.lo[i]);
 #pragma unroll 1
-        for (int i = 32; i < (N < 48 ? N : 48); i++) a.mid[i - 32] = fwd_step(i, a.mid[i - 32], c.mid[i - 32]);
-        if (N > 48) a.t0 = fwd_step(48, a.t0, c.t0);
-        if (N > 49) a.t1 = fwd_step(49, a.t1, c.t1);
+            for (int i = 32; i < (N < 48 ? N : 48); i++) a.mid[i - 32] = fwd_step(i, a.mid[i - 32], c.mid[i - 32]);
+            if (N > 48) a.t0 = fwd_step(48, a.t0, c.t0);
+            if (N > 49) a.t1 = fwd_step(49, a.t1, c.t1);
+        }
         pN = EXACT ? pterm - rho * t1 : __builtin_fmaf(-rho, t1, pterm); // admm.cpp:83-84
         const float pri_x = wave_max(is_x ? pri : 0.f), dua_x = wave_max(is_x ? dua : 0.f);
         const float pri_u = wave_max(is_u ? pri : 0.f), dua_u = wave_max(is_u ? dua : 0.f);
@@ -171,29 +222,85 @@ __global__ __launch_bounds__(WAVE, 2) void admm_waveres_kernel(const RowParams P
             break;
         }
         // ---------------- backward sweep: (v = vnew is the in-place slack) linear cost + backward_pass_grad ----------------
-        float p = pN;
         ran_bwd = true;
-        const bool upd_d = is_u && !keep_d;
-        o = rowbase + (N - 2) * WAVE;
-        float sn_cur = b[(N - 2) * WAVE];
-        auto bwd_step = [&](int i, float ai, float ci) {
-            const float cq = is_x ? ci : -0.f; // x rows: -(Xref.*Q); u rows: -0 (r = -rho*(znew - y) keeps the sign of a zero difference)
-            float pn, dd;
-            const float lin = EXACT ? cq - rho * (sn_cur - ai) : __builtin_fmaf(-rho, sn_cur - ai, cq);
-            wave_riccati_step<NX, NU, EXACT>(G, vec, lane, is_x, p, lin, pn, dd); // admm.cpp:19-20,80-82
-#if !TINY_WAVERES_ABLATE_STORES
-            P.pd[o] = is_u ? dd : pn; // [p_i ; d_i] of this sweep (live-out only)
-#endif
-            p = pn;
-            sn_cur = b[(i > 0 ? i - 1 : 0) * WAVE];
-            o -= WAVE;
-            return upd_d ? dd : ci;
-        };
-        if (N - 2 >= 48) c.t0 = bwd_step(48, a.t0, c.t0);
+        {
+            WaveGainsB<NX, NU> GB;
+            int oz;
+            asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+            GB.load(P.mats + oz, lane);
+            const bool upd_d = is_u && !keep_d;
+            const int top = N - 2;
+            int o = rowbase + top * WAVE;
+            // carried from step to step: the broadcast of p_{i+1}, the linear cost of step i and (exact) Kinf^T r_i, (fma) the broadcast r_i
+            float pv[NX], lv[NU];
+            float lin, tks = 0.f;
+            vecP[lane] = pN;
+            bcast_fetch<0, NX>(pv, vecP);
+            auto prepare = [&](float ai, float ci, float sni) { // [q ; r] of a step and what of p_i depends on it alone (admm.cpp:80-82, :20)
+                const float cq = is_x ? ci : -0.f; // x rows: -(Xref.*Q); u rows: -0 (r = -rho*(znew - y) keeps the sign of a zero difference)
+                lin = EXACT ? cq - rho * (sni - ai) : __builtin_fmaf(-rho, sni - ai, cq);
+                vecL[lane] = lin;
+                bcast_fetch<NX, NU>(lv, vecL);
+            };
+            auto finish_prepare = [&]() {
+                if constexpr (EXACT)
+                {
+                    float tk[NU];
+                    products_of(tk, GB.M45, lv); // Kinf^T * r (x rows)
+                    tks = wreduce<PL::BWD_PK>(tk);
+                }
+            };
+            prepare(a.get(top), c.get(top), b[top * WAVE]);
+            finish_prepare();
+            float sn_n = b[(top > 0 ? top - 1 : 0) * WAVE]; // slack of the NEXT step of the sweep (i - 1), fetched a step ahead
+            // one step: (an_, cn_) are the registers of step i - 1
+            auto bwd_step = [&](int i, float ci, float an_, float cn_, bool has_next) {
+                float wv, pn;
+                if constexpr (EXACT)
+                {
+                    float t[NX];
+                    products_of(t, GB.M3, pv);
+                    float dot;
+                    if constexpr (PL::BWD_PA == PL::BWD_TMP) dot = wreduce<PL::BWD_PA>(t);
+                    else dot = is_x ? wreduce<PL::BWD_PA>(t) : wreduce<PL::BWD_TMP>(t);
+                    wv = lin + dot;   // q + AmBKt*p  |  Bdyn^T*p + r
+                    pn = wv - tks;    // admm.cpp:20
+                }
+                else
+                {
+                    wv = fma_dot_of(lin, GB.M3, pv);
+                    pn = fma_dot_of(wv, GB.M45, lv); // x rows hold -Kinf^T (pack_gains, fast)
+                }
+                vecP[lane] = pn;                  // broadcast of p_i for the next step: first in the queue,
+                bcast_fetch<0, NX>(pv, vecP);
+                if (has_next) prepare(an_, cn_, sn_n); // then everything of step i - 1 that does not depend on p,
+                float wvv[NU];
+                vecW[lane] = wv;                  // then d_i = Quu_inv (Bdyn^T p + r) (admm.cpp:19)
+                bcast_fetch<NX, NU>(wvv, vecW);
+                if (has_next) finish_prepare();
+                float dd;
+                if constexpr (EXACT)
+                {
+                    float td[NU];
+                    products_of(td, GB.M45, wvv);
+                    if constexpr (PL::GEMV) dd = 0.f + (0.f + wreduce<PLAN_SEQ>(td)); // 0 + 1*(0 + dot_seq), as the GEMV path leaves it
+                    else dd = wreduce<PL::BWD_D>(td);
+                }
+                else dd = fma_dot_of(0.f, GB.M45, wvv); // u rows: Quu_inv
+                P.pd[o] = is_u ? dd : pn; // [p_i ; d_i] of this sweep (live-out only)
+                sn_n = b[(i > 1 ? i - 2 : 0) * WAVE];
+                o -= WAVE;
+                return upd_d ? dd : ci;
+            };
+            // the register of step i - 1 next to that of step i: chunk by chunk (a register tuple has at most 32 entries)
+            if (top >= 48) c.t0 = bwd_step(48, c.t0, a.mid[15], c.mid[15], true);
 #pragma unroll 1
-        for (int i = (N - 2 < 47 ? N - 2 : 47); i >= 32; i--) c.mid[i - 32] = bwd_step(i, a.mid[i - 32], c.mid[i - 32]);
+            for (int i = (top < 47 ? top : 47); i >= 33; i--) c.mid[i - 32] = bwd_step(i, c.mid[i - 32], a.mid[i - 33], c.mid[i - 33], true);
+            if (top >= 32) c.mid[0] = bwd_step(32, c.mid[0], a.lo[31], c.lo[31], true);
 #pragma unroll 1
-        for (int i = (N - 2 < 31 ? N - 2 : 31); i >= 0; i--) c.lo[i] = bwd_step(i, a.lo[i], c.lo[i]);
+            for (int i = (top < 31 ? top : 31); i >= 1; i--) c.lo[i] = bwd_step(i, c.lo[i], a.lo[i - 1], c.lo[i - 1], true);
+            c.lo[0] = bwd_step(0, c.lo[0], 0.f, 0.f, false);
+        }
     }
     if (P.max_iter <= 0) // tiny_solve only sets status and iter (admm.cpp:114-117,151)
     {
@@ -208,6 +315,10 @@ __global__ __launch_bounds__(WAVE, 2) void admm_waveres_kernel(const RowParams P
     {
         // ---------------- live-out ----------------
         const bool solved = (st == TINY_STATUS_SOLVED_);
+        WaveGains<NX, NU> G;
+        int oz;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+        G.load(P.mats + oz, lane);
         float s = x0;
         int o = rowbase;
 #pragma unroll 1
@@ -245,7 +356,7 @@ bool waveres_supported(int nx, int nu, int N) { return wavedims_supported(nx, nu
 
 hipError_t launch_admm_waveres(int nx, int nu, bool exact, const RowParams &P, hipStream_t stream)
 {
-    const size_t ldsb = (size_t)(WAVE + P.N * WAVE) * sizeof(float);
+    const size_t ldsb = (size_t)(4 * WAVE + P.N * WAVE) * sizeof(float);
 #define TINY_WAVERES_DISPATCH(NX, NU)                                                                             \
     if (nx == NX && nu == NU)                                                                                     \
     {                                                                                                             \
