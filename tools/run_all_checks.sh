@@ -12,4 +12,6 @@ python -m pytest tests/ -x -q -m "not gpu"
   timeout -k 10 $((FUZZ + 90)) python tests/fuzz/\$f.py $FUZZ 1 > gpurun_out/checks_\$f.log 2>&1; echo \"\$f: \$(tail -1 gpurun_out/checks_\$f.log | cut -c1-160)\"; done"
 /usr/local/graft/bin/gpurun --timeout 900 -- "timeout -k 10 400 python bench.py > gpurun_out/checks_bench.log 2>&1; tail -1 gpurun_out/checks_bench.log | cut -c1-400; \
   timeout -k 10 400 python bench.py --config random32 > gpurun_out/checks_bench_random32.log 2>&1; tail -1 gpurun_out/checks_bench_random32.log | cut -c1-300"
-echo "all checks ran; after a change under accelerated-tinympc_amd/csrc/ also run: bash tools/refresh_profiles.sh r02"
+echo "all checks ran; after a change under accelerated-tinympc_amd/csrc/ re-bind the committed counter figures to the new sources:"
+echo "  gpurun -- 'bash tools/collect_profiles.sh r03 0' && python tools/summarize_profiles.py r03        # the bench run itself (roofline.traffic)"
+echo "  gpurun -- 'bash tools/collect_kernel_counters.sh r03 <workloads of tools/prof_workload.py>' && python tools/summarize_kernel_counters.py r03"
