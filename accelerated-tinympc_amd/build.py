@@ -17,7 +17,7 @@ CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libtinympc_hip.so"
 WRAPPER_LIB = PKG / "lib" / "libtinympc_wrapper.so"  # same-name twin of the reference's generated wrapper library
 WRAPPER64_LIB = PKG / "lib" / "libtinympc_wrapper64.so"  # the native names (tiny_solve, forward_pass, ...) for tinytype = double
-SOURCES = ["tinympc_batch.hip", "tinympc_batch64.hip", "admm_stream.hip", "admm_rowlane.hip", "admm_rowloop.hip", "admm_quadlane.hip", "admm_tile16.hip", "admm_wave.hip", "admm_waveres.hip", "admm_steps.hip", "dispatch_order.hip", "riccati.cpp"]
+SOURCES = ["tinympc_batch.hip", "tinympc_batch64.hip", "admm_stream.hip", "admm_rowlane.hip", "admm_rowloop.hip", "admm_quadlane.hip", "admm_tile16.hip", "admm_wave.hip", "admm_waveres.hip", "admm_tile48.hip", "admm_steps.hip", "dispatch_order.hip", "riccati.cpp"]
 WRAPPER_SRCS = [CSRC / "wrapper_compat.cpp", CSRC / "admm_compat.cpp"]
 HEADERS = [CSRC / "tinympc_internal.h", CSRC / "rowlane_math.h", CSRC / "tile_math.h", CSRC / "wave_math.h", CSRC / "dpp_ops_gen.h", PKG.parent / "include" / "tinympc_batch.h", PKG.parent / "include" / "tinympc_batch64.h"]
 # -ffp-contract=off : exact arithmetic must not fuse a*b+c; the fast paths call fma explicitly
@@ -29,7 +29,8 @@ HEADERS = [CSRC / "tinympc_internal.h", CSRC / "rowlane_math.h", CSRC / "tile_ma
 # copies every one of them back, 110 v_accvgpr_read per horizon step)
 EXTRA_FLAGS = {"admm_tile16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"] + os.environ.get("TINYMPC_T16_FLAGS", "").split(),
                "admm_rowlane.hip": os.environ.get("TINYMPC_ROWLANE_FLAGS", "").split(),
-               "admm_waveres.hip": os.environ.get("TINYMPC_WAVERES_FLAGS", "").split()}
+               "admm_waveres.hip": os.environ.get("TINYMPC_WAVERES_FLAGS", "").split(),
+               "admm_tile48.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"] + os.environ.get("TINYMPC_T48_FLAGS", "").split()}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-gpu-rdc"]
 
 

@@ -237,6 +237,7 @@ struct TinyBatch
     bool row_dims_ok = false, tile_dims_ok = false, rowmath_ok = false, rowloop_ok = false, wave_ok = false, quad_ok = false;
     bool tile16_ok = false; // admm_tile16.hip has an instantiation for (nx, nu, N)
     bool waveres_ok = false; // admm_waveres.hip serves (nx, nu, N): wave class with N <= 50
+    bool tile48_ok = false;  // admm_tile48.hip does (nx = 32, nu = 16, N = 50: sixteen instances per workgroup on the matrix cores)
     int *conv_dev = nullptr; // [batch] result of termination_condition
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr; // created by tiny_batch_group_solve / mpc_run for handles left on the null stream
@@ -724,7 +725,7 @@ int resolve_variant(TinyBatch *tb, int *out)
     // per-instance bounds: the streaming row kernel and the wave kernel read them per instance; the register-resident
     // kernels stage ONE table in LDS and need batch-shared bounds
     const bool row_ok = tb->row_dims_ok || tb->rowmath_ok || tb->wave_ok;
-    if (tb->variant == VAR_ROW_FAST && tb->wave_ok && row_family(tb) != 6)
+    if (tb->variant == VAR_ROW_FAST && tb->wave_ok && row_family(tb) != 6 && row_family(tb) != 7)
         return fail(TINY_BATCH_EUNSUPPORTED, "fma arithmetic for 16 < nx + nu <= 64 needs the state-on-chip wave kernel (N <= 50); beyond that it is the streaming MFMA kernel (variant 1)");
     if (v == VAR_AUTO) v = row_ok ? VAR_ROW_EXACT : VAR_STREAM;
     if ((tb->en_uref || tb->en_d2p) && (!tb->rowmath_ok || v == VAR_STREAM))
@@ -754,10 +755,20 @@ bool tile16_applies(const TinyBatch *tb)
     return !tb->in_xref.set || tb->in_xref.shared;
 }
 
+// auto: one workgroup of three waves per sixteen instances fills the chip from 4 096 instances on (measured: 3.1 ms for any batch up to
+// 4 096 against 2.2 ms per 2 048 on the one-wave-per-instance kernel; 12.5 against 15.2 ms at 16 384, 40 fixed iterations)
+constexpr int kTile48AutoBatch = 4096;
+
 int row_family(const TinyBatch *tb)
 {
     // one wavefront per instance: state on chip where the horizon fits (admm_waveres.hip, 6), else streamed through HBM (admm_wave.hip, 3)
-    if (tb->wave_ok) return (tb->waveres_ok && tb->row_family_forced != 3) ? 6 : 3;
+    // (7: sixteen instances per workgroup on the matrix cores, admm_tile48.hip: exact arithmetic, fp32 storage)
+    if (tb->wave_ok)
+    {
+        if (tb->row_family_forced == 3) return 3;
+        if (tb->tile48_ok && tb->variant != VAR_ROW_FAST && !tb->h16 && (tb->row_family_forced == 7 || (tb->row_family_forced < 0 && tb->batch >= kTile48AutoBatch))) return 7;
+        return tb->waveres_ok ? 6 : 3;
+    }
     // per-instance bounds: the unrolled register-resident kernel (fp32 storage) and the rolled-loop ones (N <= 64, either storage)
     // read them from the [B][N][16] table, the streaming row kernel serves every other case; the quad kernel stages one shared table
     if (!bounds_all_shared(tb))
@@ -797,6 +808,7 @@ void update_kname(TinyBatch *tb)
     else if (row_family(tb) == 1) snprintf(nm, sizeof nm, "rowloop<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
     else if (row_family(tb) == 3) snprintf(nm, sizeof nm, "wavestream<%d,%d,%s>", tb->nx, tb->nu, ar);
     else if (row_family(tb) == 6) snprintf(nm, sizeof nm, "waveres<%d,%d,%s>", tb->nx, tb->nu, ar);
+    else if (row_family(tb) == 7) snprintf(nm, sizeof nm, "tile48<%d,%d,%d,%s>", tb->nx, tb->nu, tb->N, ar);
     else if (row_family(tb) == 4) snprintf(nm, sizeof nm, "quadlane<%d,%d,%d,%s%s>", tb->nx, tb->nu, tb->N, ar, sto);
     else if (row_family(tb) == 5) snprintf(nm, sizeof nm, "tile16<%d,%d,%d,%s>", tb->nx, tb->nu, tb->N, ar);
     else snprintf(nm, sizeof nm, "rowstream<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
@@ -968,6 +980,7 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
             : fam == 4 ? launch_admm_quadlane(tb->N, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
             : fam == 5 ? launch_admm_tile16(tb->N, v == VAR_ROW_EXACT, P, tb->stream)
             : fam == 6 ? launch_admm_waveres(tb->nx, tb->nu, v == VAR_ROW_EXACT, P, tb->stream)
+            : fam == 7 ? launch_admm_tile48(tb->N, P, tb->stream)
                        : launch_admm_rowstream(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream);
     }
     if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -1057,6 +1070,7 @@ int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int dev
     tb->quad_ok = tb->rowmath_ok && quadlane_supported(nx, nu, N);
     tb->tile16_ok = tb->rowmath_ok && tile16_supported(nx, nu, N);
     tb->waveres_ok = wave_ok && waveres_supported(nx, nu, N);
+    tb->tile48_ok = wave_ok && tile48_supported(nx, nu, N);
     tb->rw = wave_ok ? 64 : 16;
     tb->xfam_floats = (size_t)tb->ntiles * N * WAVE * nxc;
     tb->ufam_floats = (size_t)tb->ntiles * (N - 1) * WAVE * nuc;
@@ -1701,13 +1715,14 @@ const char *tiny_batch_kernel_name(TinyBatch *tb)
 int tiny_batch_set_row_kernel(TinyBatch *tb, int family)
 {
     CHECK_TB(tb);
-    if (family < 0 || family > 7)
-        return fail(TINY_BATCH_EINVAL, "row kernel must be 0 (auto), 1 (rowlane), 2 (rowloop), 3 (rowstream), 4 (quadlane), 5 (tile16), 6 (wavestream) or 7 (waveres)");
+    if (family < 0 || family > 8)
+        return fail(TINY_BATCH_EINVAL, "row kernel must be 0 (auto), 1 (rowlane), 2 (rowloop), 3 (rowstream), 4 (quadlane), 5 (tile16), 6 (wavestream), 7 (waveres) or 8 (tile48)");
     const bool ok = family == 0 || (family == 1 && tb->row_dims_ok) || (family == 2 && tb->rowloop_ok) || (family == 3 && tb->rowmath_ok) ||
-                    (family == 4 && tb->quad_ok) || (family == 5 && tb->tile16_ok) || (family == 6 && tb->wave_ok) || (family == 7 && tb->waveres_ok);
+                    (family == 4 && tb->quad_ok) || (family == 5 && tb->tile16_ok) || (family == 6 && tb->wave_ok) || (family == 7 && tb->waveres_ok) ||
+                    (family == 8 && tb->tile48_ok);
     if (!ok)
         return fail(TINY_BATCH_EUNSUPPORTED, "row kernel %d has no instantiation for nx=%d nu=%d N=%d", family, tb->nx, tb->nu, tb->N);
-    static const int kFam[8] = {-1, 0, 1, 2, 4, 5, 3, 6};
+    static const int kFam[9] = {-1, 0, 1, 2, 4, 5, 3, 6, 7};
     tb->row_family_forced = kFam[family];
     invalidate_graph(tb);
     return 0;

@@ -1046,11 +1046,12 @@ def test_device_pointer_io_equals_host_io(tinympc):
     sol.close(); ref.close()
 
 
-@pytest.mark.parametrize("wave_kernel", ["wavestream", "waveres"])
+@pytest.mark.parametrize("wave_kernel", ["wavestream", "waveres", "tile48"])
 @pytest.mark.parametrize("B", [1, 3, 66])
 def test_wave_kernel_vs_oracle(tinympc, oracle_mod, B, wave_kernel):
     """nx = 32, nu = 16, N = 50 (BASELINE.json configs[3]) on the two wave-per-instance exact kernels (state streamed through
-    HBM / state in registers and LDS, the default for N <= 50): bitwise equal to the
+    HBM / state in registers and LDS, the default for N <= 50 below 4 096 instances) and on the sixteen-instances-per-workgroup
+    matrix-core kernel (the default from 4 096 instances on): bitwise equal to the
     oracle (== the compiled reference for this class, tests/test_oracle.py) over a warm-started chain, with early exit,
     sparse termination checks, one iteration, bounds disabled and a random time-varying reference."""
     O, pr = oracle_mod, tinympc.problems
@@ -1065,8 +1066,8 @@ def test_wave_kernel_vs_oracle(tinympc, oracle_mod, B, wave_kernel):
         settings = dict(O.DEFAULT_SETTINGS, **settings)
         sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
         assert sol.kernel_name() == "waveres<32,16,exact>", sol.kernel_name()   # the automatic choice
-        sol.set_row_kernel(6 if wave_kernel == "wavestream" else 7)
-        assert sol.kernel_name() == f"{wave_kernel}<32,16,exact>", sol.kernel_name()
+        sol.set_row_kernel({"wavestream": 6, "waveres": 7, "tile48": 8}[wave_kernel])
+        assert sol.kernel_name() == (f"{wave_kernel}<32,16,exact>" if wave_kernel != "tile48" else "tile48<32,16,50,exact>"), sol.kernel_name()
         sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
         orc = O.Oracle(prob, np.float32, settings)
         st = O.new_state(B, nx, nu, N); st["x"][:, 0] = x0
@@ -1089,6 +1090,54 @@ def test_wave_kernel_vs_oracle(tinympc, oracle_mod, B, wave_kernel):
         for name in STATE_ORDER:
             assert np.array_equal(got[name], st[name]), f"layout switch lost {name}"
         sol.close()
+
+
+@pytest.mark.parametrize("N", [50, 37, 2])
+def test_tile48_kernel_equals_wave_kernel_bitwise(tinympc, N):
+    """admm_tile48.hip (sixteen instances per workgroup, products on the matrix cores, duals in LDS, slack streamed through its own
+    array) against the one-wave-per-instance kernel it replaces for large batches: every work array, residuals, iteration counts
+    and status bit for bit — ragged batches (columns past the batch), per-instance bounds, window of a trajectory table as the
+    reference, warm-started chains in which the columns of a tile converge at different iterations, sparse termination checks,
+    horizons below the capacity of 50; and the automatic choice from 4 096 instances on."""
+    pr = tinympc.problems
+    nx, nu = 32, 16
+    prob = pr.random_system(nx, nu, N)
+    shared = pr.bounds_arrays(prob)
+    for B, settings, per_inst, window in ((4096, dict(max_iter=30), False, False), (1000, dict(max_iter=100, abs_pri_tol=3e-2, abs_dua_tol=3e-2), True, False),
+                                         (37, dict(max_iter=60, check_termination=7, abs_pri_tol=3e-2, abs_dua_tol=3e-2), False, True), (16, dict(max_iter=1), True, True)):
+        s = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1, en_state_bound=1, en_input_bound=1); s.update(settings)
+        rng = np.random.default_rng(B + N)
+        x0 = rng.uniform(-1, 1, size=(B, nx)).astype(np.float32)
+        bnds = tuple((a[None] * rng.uniform(0.2, 1.0, size=(B,) + a.shape)).astype(np.float32) for a in shared) if per_inst else shared
+        sols = []
+        for fam in (7, 8):
+            sol = tinympc.TinyBatchSolver(prob, B, settings=s)
+            if B >= 4096 and N == 50:
+                assert sol.kernel_name() == "tile48<32,16,50,exact>", sol.kernel_name()   # the automatic choice
+            sol.set_row_kernel(fam)
+            assert sol.kernel_name() == (f"waveres<32,16,exact>" if fam == 7 else f"tile48<32,16,{N},exact>"), sol.kernel_name()
+            sol.set_bounds(*bnds)
+            if window:
+                table = (rng.standard_normal((N + 40, nx)) * 0.2).astype(np.float32) if fam == 7 else table
+                start = rng.integers(0, 41, size=B).astype(np.int32) if fam == 7 else start
+                sol.set_xref_window(table, start)
+            else:
+                xref = (rng.standard_normal((B, N, nx)) * 0.2).astype(np.float32) if fam == 7 else xref
+                sol.set_xref(xref)
+            sol.set_x0(x0)
+            sols.append(sol)
+        for k in range(3):
+            sts = []
+            for sol in sols:
+                if k == 1:
+                    sol.reset_dual_variables()
+                rc = sol.solve(); st = sol.get_state(); st["rc"] = np.array([rc]); sts.append(st)
+            for name in sts[0]:
+                assert np.asarray(sts[0][name]).tobytes() == np.asarray(sts[1][name]).tobytes(), f"tile48 vs waveres: {name}, B={B} N={N} {settings} k={k}"
+            if B == 1000 and N == 50 and k == 0:
+                assert len(np.unique(sts[1]["iter"])) > 3, "the columns of a tile should stop at different iterations in this case"
+        for sol in sols:
+            sol.close()
 
 
 @pytest.mark.parametrize("dims", [(32, 16, 50), (16, 8, 49), (16, 4, 33), (20, 8, 21)])

@@ -32,6 +32,8 @@ WORKLOADS = {
     "waveres_exact": dict(prob="r32", batch=16384, ref="zero", variant=2, family=7),
     "waveres_exact_2048": dict(prob="r32", batch=2048, ref="zero", variant=2, family=7),
     "waveres_fast": dict(prob="r32", batch=16384, ref="zero", variant=3, family=7),
+    "tile48_exact": dict(prob="r32", batch=16384, ref="zero", variant=2, family=8),
+    "tile48_exact_2048": dict(prob="r32", batch=2048, ref="zero", variant=2, family=8),
     "wavestream_exact": dict(prob="r32", batch=16384, ref="zero", variant=2, family=6),
     "stream_8_4": dict(prob="r32", batch=16384, ref="zero", variant=1, family=0),
     "rows64": dict(prob="q30", batch=65536, ref="track", f64=True, which=2),
