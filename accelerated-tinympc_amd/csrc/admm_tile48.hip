@@ -147,6 +147,14 @@ __device__ __forceinline__ t48v4 t48_reduce(const t48v4 (&t)[NN])
 #ifndef T48_TIE
 #define T48_TIE 0 // measured: tying the order of the matrix-core instructions to the sums costs 5 % once nothing spills
 #endif
+#ifndef T48_PROFILE
+#define T48_PROFILE 0 // timing experiment only (the residual fields of instances 0..7 are overwritten): clocks of block 0 per phase
+#endif
+#if T48_PROFILE
+#define T48_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof[k] += (float)(now_ - tprev); tprev = now_; } while (0)
+#else
+#define T48_STAMP(k) do { } while (0)
+#endif
 #ifndef T48_ABLATE
 #define T48_ABLATE 0 // timing experiments only (results are wrong): 1 = no backward sweep, 2 = no write-through stores
 #endif
@@ -344,6 +352,8 @@ __device__ __forceinline__ void t48_x_role(const RowParams &P, float *lds, int w
     t48v16 negz;
 #pragma unroll
     for (int e = 0; e < 16; e++) negz[e] = -0.f;
+    asm volatile("" : "+v"(negz)); // a value the compiler cannot rebuild: as a known constant it lets the last product of every stage overwrite
+                                   // the tuple and re-materialises it (16 scalar + 8 vector moves per stage, five stages per step pair)
     // gains: A operands, lane (g, c) supplies column 4m + g of tile row c
     const float *const mrow = P.mats + row0 + c;
     float A1[8], A2[4], A3[8], A45[4];
@@ -405,6 +415,10 @@ __device__ __forceinline__ void t48_x_role(const RowParams &P, float *lds, int w
     t48v4 pN = z4;
     bool ran_bwd = false, act = valid;
     int rp = 0;
+#if T48_PROFILE
+    float prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+#endif
 
     for (int it = 0; it < P.max_iter; ++it)
     {
@@ -431,9 +445,7 @@ __device__ __forceinline__ void t48_x_role(const RowParams &P, float *lds, int w
                 C.bounds(P, i + 1, lo_n, hi_n);
                 const t48v4 bold_n = t48_ld4(S + off + WAVE);
                 t48v4 acc = t48_dot<PL::FWD_XA, 32>(A1, xB, negz); // Adyn x_i (admm.cpp:35)
-                t48_barrier_after(acc); // u_i is there
-                float uB[4];
-                t48_fetch<16>(uB, UB, g, c);
+                // the slack / dual update of the x rows needs nothing of u_i: it runs while the u wave finishes u_i
                 const t48v4 aold = C.dual[i * WAVE];
                 t48v4 tn, an;
                 t48_slack_dual(s, aold, bold, lo, hi, tn, an, pri, dua);
@@ -441,9 +453,18 @@ __device__ __forceinline__ void t48_x_role(const RowParams &P, float *lds, int w
                 t48_wt4(s_dst + off, tn);    // vnew_i
                 t48_wt4(vz_dst + off, bold); // v_i, should this iteration converge
                 t48_wt4(xu_dst + off, s);    // x_i of this sweep (live-out only)
-                const t48v4 xn = acc + t48_dot<PL::FWD_XB, 16>(A2, uB, negz); // x_{i+1} = Adyn x_i + Bdyn u_i
+                asm volatile("" : "+v"(acc));
+                T48_STAMP(0);
+                t48_barrier_after(acc); // u_i is there
+                T48_STAMP(1);
+                float uB[4];
+                t48_fetch<16>(uB, UB, g, c);
+                t48v4 xn = acc + t48_dot<PL::FWD_XB, 16>(A2, uB, negz); // x_{i+1} = Adyn x_i + Bdyn u_i
                 t48_put(XB + (par ^ 1) * 512, row0, g, c, xn);
+                asm volatile("" : "+v"(xn));
+                T48_STAMP(2);
                 t48_barrier(); // x_{i+1} is there
+                T48_STAMP(3);
                 par ^= 1;
                 t48_fetch<32>(xB, XB + par * 512, g, c);
                 s = xn; lo = lo_n; hi = hi_n; bold = bold_n;
@@ -501,15 +522,24 @@ __device__ __forceinline__ void t48_x_role(const RowParams &P, float *lds, int w
                 const int i2 = i > 1 ? i - 2 : 0;
                 xr_n = xref_at(i2);
                 sn_n = t48_ld4(S + C.base + i2 * WAVE);
-                const t48v4 wv = lin + t48_dot<PL::BWD_PA, 32>(A3, pB, negz); // q + AmBKt p
+                t48v4 wv = lin + t48_dot<PL::BWD_PA, 32>(A3, pB, negz); // q + AmBKt p
+#if T48_PROFILE
+                asm volatile("" : "+v"(wv));
+                T48_STAMP(7);
+#endif
                 t48v4 pn = wv - tks;                                           // admm.cpp:20
                 t48_put(XB + (q ^ 1) * 512, row0, g, c, pn);
                 t48_wt4(pd_dst + off, pn); // p_i of this sweep (live-out only)
                 if (i > 0) lin = linear(C.dual[(i - 1) * WAVE], xr, sn);
+                asm volatile("" : "+v"(pn), "+v"(lin));
+                T48_STAMP(4);
                 t48_barrier_after(pn); // p_i and r_{i-1} are there
+                T48_STAMP(5);
                 q ^= 1;
                 t48_fetch<32>(pB, XB + q * 512, g, c);
                 if (i > 0) fetch_r(RB + q * 256);
+                asm volatile("" : "+v"(tks));
+                T48_STAMP(6);
             }
         }
     }
@@ -540,6 +570,10 @@ __device__ __forceinline__ void t48_x_role(const RowParams &P, float *lds, int w
                 P.iter[C.inst] = itn;
                 if (!solved) atomicAdd(P.n_unsolved, 1);
             }
+#if T48_PROFILE
+            if (blockIdx.x == 0 && wid == 0 && C.lane == 0)
+                for (int k = 0; k < 8; k++) P.res[k] = prof[k];
+#endif
         }
     }
 }
@@ -559,6 +593,8 @@ __device__ __forceinline__ void t48_u_role(const RowParams &P, float *lds)
     t48v16 negz;
 #pragma unroll
     for (int e = 0; e < 16; e++) negz[e] = -0.f;
+    asm volatile("" : "+v"(negz)); // a value the compiler cannot rebuild: as a known constant it lets the last product of every stage overwrite
+                                   // the tuple and re-materialises it (16 scalar + 8 vector moves per stage, five stages per step pair)
     const float *const mrow = P.mats + T48_NX + c;
     float A1[8], A3[8], A45[4]; // Kinf rows | Bdyn^T rows | Quu_inv rows
 #pragma unroll
@@ -666,21 +702,19 @@ __device__ __forceinline__ void t48_u_role(const RowParams &P, float *lds)
                 sn_n = t48_ld4(S + C.base + (i > 1 ? i - 2 : 0) * WAVE);
                 const t48v4 wv = lin + t48_dot<PL::BWD_TMP, 32>(A3, pB, negz); // Bdyn^T p + r
                 t48_put(UB, 0, g, c, wv); // d_i = Quu_inv (Bdyn^T p + r) (admm.cpp:19): this exchange stays inside the wave
-                t48_fence();
-                t48_fetch<16>(wB, UB, g, c);
-                t48_fence();
                 if (i > 0)
                 {
                     lin = linear(C.dual[(i - 1) * WAVE], sn);
                     t48_put(RB + (q ^ 1) * 256, 0, g, c, lin);
                 }
+                t48_barrier_after(lin); // p_i and r_{i-1} are there; d_i, which nobody waits for, is computed behind the barrier
+                q ^= 1;
+                t48_fetch<16>(wB, UB, g, c);
+                t48_fetch<32>(pB, XB + q * 512, g, c);
                 t48v4 dd;
                 if constexpr (PL::GEMV) dd = z4 + (z4 + t48_dot<PLAN_SEQ, 16>(A45, wB, negz)); // 0 + 1*(0 + dot_seq), as the GEMV path leaves it
                 else dd = t48_dot<PL::BWD_D, 16>(A45, wB, negz);
                 t48_wt4(pd_dst + off, dd); // d_i of this sweep: the next forward sweep reads it back
-                t48_barrier_after(dd); // p_i and r_{i-1} are there
-                q ^= 1;
-                t48_fetch<32>(pB, XB + q * 512, g, c);
             }
         }
     }
