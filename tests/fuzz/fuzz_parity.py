@@ -33,7 +33,7 @@ pr = T.problems
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 CLASSES = [("quad", 30), ("quad", 25), ("quad", 20), ("quad", 10), ("quad", 17), ("quad", 7), ("quad", 36), ("quad", 40), ("quad", 50), ("quad", 61), ("quad", 67), ("cartpole", 10),
-           ("cartpole", 23), ("odd", 7), ("odd", 13), ("rand32", 50), ("r8_4", 9), ("r12_2", 14), ("r4_2", 8), ("r4_4", 35), ("w16_8", 10), ("w16_4", 12), ("w20_8", 11), ("w24_4", 9)]
+           ("cartpole", 23), ("odd", 7), ("odd", 13), ("rand32", 50), ("rand32", 50), ("rand32", 23), ("rand32", 2), ("r8_4", 9), ("r12_2", 14), ("r4_2", 8), ("r4_4", 35), ("w16_8", 10), ("w16_4", 12), ("w20_8", 11), ("w24_4", 9)]
 t_end, rounds, solves, t_note, overflowed, refused = time.time() + budget, 0, 0, time.time(), 0, 0
 while time.time() < t_end:
     if time.time() - t_note > 30:
@@ -47,7 +47,7 @@ while time.time() < t_end:
                 "rand32": lambda: pr.random_system(32, 16, N)}[kind]()
     nx, nu = prob["nx"], prob["nu"]
     wave = kind == "rand32" or kind.startswith("w")
-    B = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 200])) if not wave else int(rng.choice([1, 3, 9]))
+    B = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 200])) if not wave else int(rng.choice([1, 3, 9, 17, 40]))
     settings = dict(abs_pri_tol=float(rng.choice([0.0, 1e-3, 1e-2, 0.5])), abs_dua_tol=float(rng.choice([0.0, 1e-3, 1e-1, 5.0])),
                     max_iter=int(rng.choice([0, 1, 2, 3, 7, 20, 45])), check_termination=int(rng.choice([1, 1, 2, 3, 7])),
                     en_state_bound=int(rng.integers(2)), en_input_bound=int(rng.integers(2)))
@@ -73,7 +73,7 @@ while time.time() < t_end:
             except T.TinyBatchError:
                 pass
     R = O.round_h16 if h16 else (lambda a: a)
-    fams = [0] + ([1, 2, 3, 4, 5] if not wave else [6, 7])   # 5 = tile16 (MFMA products), 6 / 7 = streaming / on-chip wave kernel
+    fams = [0] + ([1, 2, 3, 4, 5] if not wave else [6, 7, 8, 8])   # 5 = tile16 (MFMA products), 6 / 7 = streaming / on-chip wave kernel, 8 = tile48 (nx = 32)
     fam = int(rng.choice(fams))
     try:
         sol.set_row_kernel(fam)
