@@ -23,7 +23,10 @@
 //     an array the live-out rewrites anyway.
 // Sixteen instances run in lock step (state updates of a finished column are selects on its `active` flag); the workgroup ends when
 // its last column has.  Arithmetic, orders and results are those of admm_waveres.hip: bitwise equal to the compiled reference.
-// Scope: nx = 32, nu = 16, N <= 50 (the LDS holds 50 steps of duals), exact arithmetic, fp32 storage.
+// Two arithmetic modes like the wave kernels: EXACT (above) and fma (template parameter false): every stage ONE k-ascending fma chain
+// of v_mfma_f32_16x16x4_f32 started from its additive term — no vector sums at all —, held to the bar of every other fma variant (the
+// reference's own fp64/fp32 spread).
+// Scope: nx = 32, nu = 16, N <= 50 (the LDS holds 50 steps of duals), fp32 storage.
 #include "wave_math.h"
 #include <atomic>
 
@@ -251,6 +254,15 @@ __device__ __forceinline__ t48v4 t48_dot(const float (&A)[CNT / 4], const float 
         return (sj[0] + sj[2]) + (sj[1] + sj[3]);
     }
 }
+// fma arithmetic: init + sum_k M[rows][k] * s_c[k] as ONE k-ascending fma chain on the matrix cores (v_mfma_f32_16x16x4_f32 accumulates its
+// four columns in order); a chain that starts a sum is started from -0, so that its first link is a plain product (admm_tile16.hip)
+template <int CNT>
+__device__ __forceinline__ t48v4 t48_chain(t48v4 acc, const float (&A)[CNT / 4], const float (&B)[CNT / 4])
+{
+#pragma unroll
+    for (int m = 0; m < CNT / 4; m++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m], B[m], acc, 0, 0, 0);
+    return acc;
+}
 __device__ __forceinline__ float t48_colmax(float v) // max over the four lanes (g = 0..3) that hold one column's rows
 {
     v = fmaxf(v, __shfl_xor(v, 16));
@@ -340,6 +352,7 @@ __device__ __forceinline__ void t48_slack_dual(const t48v4 &sv, const t48v4 &aol
 // ------------------------------------------------------------------------------------------------------------------------------
 // x waves (wid 0, 1): 16 x rows each
 // ------------------------------------------------------------------------------------------------------------------------------
+template <bool EXACT>
 __device__ __forceinline__ void t48_x_role(const RowParams &P, float *lds, int wid)
 {
     using PL = WavePlans<T48_NX, T48_NU>;
@@ -402,7 +415,8 @@ __device__ __forceinline__ void t48_x_role(const RowParams &P, float *lds, int w
         t48_put(XB, row0, g, c, xref_at(N - 1));
         t48_barrier();
         t48_fetch<32>(xB, XB, g, c);
-        pterm = -t48_dot<PL::TERM, 32>(AP, xB, negz);
+        if constexpr (EXACT) pterm = -t48_dot<PL::TERM, 32>(AP, xB, negz);
+        else pterm = -t48_chain<32>(t48v4{-0.f, -0.f, -0.f, -0.f}, AP, xB);
         t48_barrier_after(pterm); // XB is reused by the sweep
     }
     int st = TINY_STATUS_UNSOLVED_, itn = 1;
@@ -444,7 +458,9 @@ __device__ __forceinline__ void t48_x_role(const RowParams &P, float *lds, int w
                 t48v4 lo_n, hi_n;
                 C.bounds(P, i + 1, lo_n, hi_n);
                 const t48v4 bold_n = t48_ld4(S + off + WAVE);
-                t48v4 acc = t48_dot<PL::FWD_XA, 32>(A1, xB, negz); // Adyn x_i (admm.cpp:35)
+                t48v4 acc; // Adyn x_i (admm.cpp:35)
+                if constexpr (EXACT) acc = t48_dot<PL::FWD_XA, 32>(A1, xB, negz);
+                else acc = t48_chain<32>(t48v4{-0.f, -0.f, -0.f, -0.f}, A1, xB);
                 // the slack / dual update of the x rows needs nothing of u_i: it runs while the u wave finishes u_i
                 const t48v4 aold = C.dual[i * WAVE];
                 t48v4 tn, an;
@@ -459,7 +475,9 @@ __device__ __forceinline__ void t48_x_role(const RowParams &P, float *lds, int w
                 T48_STAMP(1);
                 float uB[4];
                 t48_fetch<16>(uB, UB, g, c);
-                t48v4 xn = acc + t48_dot<PL::FWD_XB, 16>(A2, uB, negz); // x_{i+1} = Adyn x_i + Bdyn u_i
+                t48v4 xn; // x_{i+1} = Adyn x_i + Bdyn u_i
+                if constexpr (EXACT) xn = acc + t48_dot<PL::FWD_XB, 16>(A2, uB, negz);
+                else xn = t48_chain<16>(acc, A2, uB);
                 t48_put(XB + (par ^ 1) * 512, row0, g, c, xn);
                 asm volatile("" : "+v"(xn));
                 T48_STAMP(2);
@@ -483,7 +501,12 @@ __device__ __forceinline__ void t48_x_role(const RowParams &P, float *lds, int w
         }
         if (act)
         {
-            pN = pterm - rho * t1; // admm.cpp:83-84
+            if constexpr (EXACT) pN = pterm - rho * t1; // admm.cpp:83-84
+            else
+            {
+#pragma unroll
+                for (int j = 0; j < 4; j++) pN[j] = __builtin_fmaf(-rho, t1[j], pterm[j]);
+            }
             itn = it + 1;
         }
         if ((it + 1) % P.check_termination == 0) t48_check(P, C, pri, dua, rp, act, st, r_ps, r_pi, r_ds, r_di);
@@ -496,16 +519,16 @@ __device__ __forceinline__ void t48_x_role(const RowParams &P, float *lds, int w
             float *const pd_dst = act ? P.pd : P.qr; // (after the check: a column that has just converged keeps the p of its last sweep)
             float pB[8], rB[4];
             int q = 0;
-            t48v4 lin, tks;
+            t48v4 lin, tks = z4;
             auto linear = [&](const t48v4 &ai, const t48v4 &xr, const t48v4 &sn) -> t48v4 { // q_i = -(Xref_i .* Q) - rho (vnew_i - g_i) (admm.cpp:81-82)
                 t48v4 l;
 #pragma unroll
-                for (int j = 0; j < 4; j++) l[j] = -(xr[j] * qrow[j]) - rho * (sn[j] - ai[j]);
+                for (int j = 0; j < 4; j++) l[j] = EXACT ? -(xr[j] * qrow[j]) - rho * (sn[j] - ai[j]) : __builtin_fmaf(-rho, sn[j] - ai[j], -(xr[j] * qrow[j]));
                 return l;
             };
             auto fetch_r = [&](const float *src) { // Kinf^T r_i (admm.cpp:20)
                 t48_fetch<16>(rB, src, g, c);
-                tks = t48_dot<PL::BWD_PK, 16>(A45, rB, negz);
+                if constexpr (EXACT) tks = t48_dot<PL::BWD_PK, 16>(A45, rB, negz);
             };
             lin = linear(C.dual[top * WAVE], xref_at(top), t48_ld4(S + C.base + top * WAVE));
             // the reference row and the slack of the next step (i - 1), loaded a step ahead
@@ -522,12 +545,16 @@ __device__ __forceinline__ void t48_x_role(const RowParams &P, float *lds, int w
                 const int i2 = i > 1 ? i - 2 : 0;
                 xr_n = xref_at(i2);
                 sn_n = t48_ld4(S + C.base + i2 * WAVE);
-                t48v4 wv = lin + t48_dot<PL::BWD_PA, 32>(A3, pB, negz); // q + AmBKt p
+                t48v4 wv; // q + AmBKt p
+                if constexpr (EXACT) wv = lin + t48_dot<PL::BWD_PA, 32>(A3, pB, negz);
+                else wv = t48_chain<32>(lin, A3, pB);
 #if T48_PROFILE
                 asm volatile("" : "+v"(wv));
                 T48_STAMP(7);
 #endif
-                t48v4 pn = wv - tks;                                           // admm.cpp:20
+                t48v4 pn; // admm.cpp:20
+                if constexpr (EXACT) pn = wv - tks;
+                else pn = t48_chain<16>(wv, A45, rB); // x rows of M45 hold -Kinf^T (pack_gains, fast)
                 t48_put(XB + (q ^ 1) * 512, row0, g, c, pn);
                 t48_wt4(pd_dst + off, pn); // p_i of this sweep (live-out only)
                 if (i > 0) lin = linear(C.dual[(i - 1) * WAVE], xr, sn);
@@ -555,7 +582,7 @@ __device__ __forceinline__ void t48_x_role(const RowParams &P, float *lds, int w
                 const t48v4 sn = t48_ld4(S + off), xr = xref_at(i), av = C.dual[i * WAVE];
                 t48v4 lq;
 #pragma unroll
-                for (int j = 0; j < 4; j++) lq[j] = -(xr[j] * qrow[j]) - rho * (sn[j] - av[j]);
+                for (int j = 0; j < 4; j++) lq[j] = EXACT ? -(xr[j] * qrow[j]) - rho * (sn[j] - av[j]) : __builtin_fmaf(-rho, sn[j] - av[j], -(xr[j] * qrow[j]));
                 t48_st4(P.qr + off, lq);
                 if (i == N - 1) t48_st4(P.pd + off, pN);
                 else if (cold && !ran_bwd) t48_st4(P.pd + off, z4);
@@ -581,6 +608,7 @@ __device__ __forceinline__ void t48_x_role(const RowParams &P, float *lds, int w
 // ------------------------------------------------------------------------------------------------------------------------------
 // u wave (wid 2): the 16 u rows; d comes back from the pd array one step ahead
 // ------------------------------------------------------------------------------------------------------------------------------
+template <bool EXACT>
 __device__ __forceinline__ void t48_u_role(const RowParams &P, float *lds)
 {
     using PL = WavePlans<T48_NX, T48_NU>;
@@ -644,10 +672,14 @@ __device__ __forceinline__ void t48_u_role(const RowParams &P, float *lds)
                 C.bounds(P, i + 1, lo_n, hi_n);
                 const t48v4 bold_n = t48_ld4(S + off + WAVE);
                 const t48v4 d_n = (d_zero || i + 1 >= N - 1) ? z4 : t48_ld4(P.pd + off + WAVE);
-                const t48v4 acc = t48_dot<PL::FWD_U, 32>(A1, xB, negz); // u_i = -Kinf x_i - d_i (admm.cpp:31)
-                t48v4 un;
+                t48v4 un; // u_i = -Kinf x_i - d_i (admm.cpp:31)
+                if constexpr (EXACT)
+                {
+                    const t48v4 acc = t48_dot<PL::FWD_U, 32>(A1, xB, negz);
 #pragma unroll
-                for (int j = 0; j < 4; j++) un[j] = -acc[j] - di[j];
+                    for (int j = 0; j < 4; j++) un[j] = -acc[j] - di[j];
+                }
+                else un = t48_chain<32>(t48v4{-0.f, -0.f, -0.f, -0.f}, A1, xB) - di; // u rows of M1 hold -Kinf (pack_gains, fast)
                 t48_put(UB, 0, g, c, un);
                 t48_barrier_after(un); // u_i is there
                 const t48v4 aold = C.dual[i * WAVE];
@@ -686,7 +718,7 @@ __device__ __forceinline__ void t48_u_role(const RowParams &P, float *lds)
             auto linear = [&](const t48v4 &ai, const t48v4 &sn) -> t48v4 { // r_i = -rho (znew_i - y_i): -0 + ... keeps the sign of a zero difference (admm.cpp:80)
                 t48v4 l;
 #pragma unroll
-                for (int j = 0; j < 4; j++) l[j] = -0.f - rho * (sn[j] - ai[j]);
+                for (int j = 0; j < 4; j++) l[j] = EXACT ? -0.f - rho * (sn[j] - ai[j]) : __builtin_fmaf(-rho, sn[j] - ai[j], -0.f);
                 return l;
             };
             t48v4 lin = linear(C.dual[top * WAVE], t48_ld4(S + C.base + top * WAVE));
@@ -700,7 +732,9 @@ __device__ __forceinline__ void t48_u_role(const RowParams &P, float *lds)
                 const int off = C.base + i * WAVE;
                 const t48v4 sn = sn_n;
                 sn_n = t48_ld4(S + C.base + (i > 1 ? i - 2 : 0) * WAVE);
-                const t48v4 wv = lin + t48_dot<PL::BWD_TMP, 32>(A3, pB, negz); // Bdyn^T p + r
+                t48v4 wv; // Bdyn^T p + r
+                if constexpr (EXACT) wv = lin + t48_dot<PL::BWD_TMP, 32>(A3, pB, negz);
+                else wv = t48_chain<32>(lin, A3, pB);
                 t48_put(UB, 0, g, c, wv); // d_i = Quu_inv (Bdyn^T p + r) (admm.cpp:19): this exchange stays inside the wave
                 if (i > 0)
                 {
@@ -712,7 +746,8 @@ __device__ __forceinline__ void t48_u_role(const RowParams &P, float *lds)
                 t48_fetch<16>(wB, UB, g, c);
                 t48_fetch<32>(pB, XB + q * 512, g, c);
                 t48v4 dd;
-                if constexpr (PL::GEMV) dd = z4 + (z4 + t48_dot<PLAN_SEQ, 16>(A45, wB, negz)); // 0 + 1*(0 + dot_seq), as the GEMV path leaves it
+                if constexpr (!EXACT) dd = t48_chain<16>(t48v4{-0.f, -0.f, -0.f, -0.f}, A45, wB);
+                else if constexpr (PL::GEMV) dd = z4 + (z4 + t48_dot<PLAN_SEQ, 16>(A45, wB, negz)); // 0 + 1*(0 + dot_seq), as the GEMV path leaves it
                 else dd = t48_dot<PL::BWD_D, 16>(A45, wB, negz);
                 t48_wt4(pd_dst + off, dd); // d_i of this sweep: the next forward sweep reads it back
             }
@@ -730,7 +765,7 @@ __device__ __forceinline__ void t48_u_role(const RowParams &P, float *lds)
                 const t48v4 sn = t48_ld4(S + off), av = C.dual[i * WAVE];
                 t48v4 lr;
 #pragma unroll
-                for (int j = 0; j < 4; j++) lr[j] = -0.f - rho * (sn[j] - av[j]);
+                for (int j = 0; j < 4; j++) lr[j] = EXACT ? -0.f - rho * (sn[j] - av[j]) : __builtin_fmaf(-rho, sn[j] - av[j], -0.f);
                 t48_st4(P.qr + off, i < N - 1 ? lr : z4);
                 if (i == N - 1) t48_st4(P.pd + off, z4);
                 else if (cold && !ran_bwd) t48_st4(P.pd + off, z4);
@@ -741,6 +776,7 @@ __device__ __forceinline__ void t48_u_role(const RowParams &P, float *lds)
     }
 }
 
+template <bool EXACT>
 __global__ __launch_bounds__(3 * WAVE, 1) void admm_tile48_kernel(const RowParams P)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -756,17 +792,17 @@ __global__ __launch_bounds__(3 * WAVE, 1) void admm_tile48_kernel(const RowParam
         }
         return;
     }
-    if (wid < 2) t48_x_role(P, lds, wid);
-    else t48_u_role(P, lds);
+    if (wid < 2) t48_x_role<EXACT>(P, lds, wid);
+    else t48_u_role<EXACT>(P, lds);
 }
 } // namespace
 
 constexpr int T48_MAX_N = 50;
 bool tile48_supported(int nx, int nu, int N) { return nx == T48_NX && nu == T48_NU && N >= 2 && N <= T48_MAX_N; }
 
-hipError_t launch_admm_tile48(int N, const RowParams &P, hipStream_t stream)
+template <bool EXACT>
+static hipError_t t48_launch(int N, const RowParams &P, hipStream_t stream)
 {
-    if (N < 2 || N > T48_MAX_N) return hipErrorInvalidValue;
     const size_t ldsb = t48_lds_bytes(N);
     static std::atomic<unsigned long long> done{0};
     int dev = 0;
@@ -774,12 +810,18 @@ hipError_t launch_admm_tile48(int N, const RowParams &P, hipStream_t stream)
     if (e != hipSuccess) return e;
     if (dev >= 64 || !((done.load() >> dev) & 1ull))
     {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&admm_tile48_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t48_lds_bytes(T48_MAX_N));
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&admm_tile48_kernel<EXACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t48_lds_bytes(T48_MAX_N));
         if (e != hipSuccess) return e;
         if (dev < 64) done.fetch_or(1ull << dev);
     }
-    hipLaunchKernelGGL(admm_tile48_kernel, dim3((P.batch + T48_COLS - 1) / T48_COLS), dim3(3 * WAVE), ldsb, stream, P);
+    hipLaunchKernelGGL(admm_tile48_kernel<EXACT>, dim3((P.batch + T48_COLS - 1) / T48_COLS), dim3(3 * WAVE), ldsb, stream, P);
     return hipGetLastError();
+}
+
+hipError_t launch_admm_tile48(int N, bool exact, const RowParams &P, hipStream_t stream)
+{
+    if (N < 2 || N > T48_MAX_N) return hipErrorInvalidValue;
+    return exact ? t48_launch<true>(N, P, stream) : t48_launch<false>(N, P, stream);
 }
 
 } // namespace tinympc

@@ -762,11 +762,11 @@ constexpr int kTile48AutoBatch = 4096;
 int row_family(const TinyBatch *tb)
 {
     // one wavefront per instance: state on chip where the horizon fits (admm_waveres.hip, 6), else streamed through HBM (admm_wave.hip, 3)
-    // (7: sixteen instances per workgroup on the matrix cores, admm_tile48.hip: exact arithmetic, fp32 storage)
+    // (7: sixteen instances per workgroup on the matrix cores, admm_tile48.hip: fp32 storage)
     if (tb->wave_ok)
     {
         if (tb->row_family_forced == 3) return 3;
-        if (tb->tile48_ok && tb->variant != VAR_ROW_FAST && !tb->h16 && (tb->row_family_forced == 7 || (tb->row_family_forced < 0 && tb->batch >= kTile48AutoBatch))) return 7;
+        if (tb->tile48_ok && !tb->h16 && (tb->row_family_forced == 7 || (tb->row_family_forced < 0 && tb->batch >= kTile48AutoBatch))) return 7;
         return tb->waveres_ok ? 6 : 3;
     }
     // per-instance bounds: the unrolled register-resident kernel (fp32 storage) and the rolled-loop ones (N <= 64, either storage)
@@ -980,7 +980,7 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
             : fam == 4 ? launch_admm_quadlane(tb->N, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
             : fam == 5 ? launch_admm_tile16(tb->N, v == VAR_ROW_EXACT, P, tb->stream)
             : fam == 6 ? launch_admm_waveres(tb->nx, tb->nu, v == VAR_ROW_EXACT, P, tb->stream)
-            : fam == 7 ? launch_admm_tile48(tb->N, P, tb->stream)
+            : fam == 7 ? launch_admm_tile48(tb->N, v == VAR_ROW_EXACT, P, tb->stream)
                        : launch_admm_rowstream(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream);
     }
     if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));

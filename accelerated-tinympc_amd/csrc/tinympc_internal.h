@@ -149,9 +149,9 @@ hipError_t launch_admm_wavestream(int nx, int nu, const RowParams &P, hipStream_
 // the same classes with the loop-carried state on chip (admm_waveres.hip): N <= 50
 bool waveres_supported(int nx, int nu, int N);
 hipError_t launch_admm_waveres(int nx, int nu, bool exact, const RowParams &P, hipStream_t stream);
-// nx = 32, nu = 16, N = 50 with sixteen instances per workgroup on the matrix cores (admm_tile48.hip): exact arithmetic
+// nx = 32, nu = 16, N <= 50 with sixteen instances per workgroup on the matrix cores (admm_tile48.hip): exact and fma arithmetic
 bool tile48_supported(int nx, int nu, int N);
-hipError_t launch_admm_tile48(int N, const RowParams &P, hipStream_t stream);
+hipError_t launch_admm_tile48(int N, bool exact, const RowParams &P, hipStream_t stream);
 
 hipError_t launch_admm_stream(int nxc, int nuc, const SolveParams &P, hipStream_t stream);
 

@@ -201,7 +201,7 @@ extern "C"
      * nu = 4 and an instantiated horizon; on request only; with a per-instance reference array or fp16 storage the handle
      * falls back to the auto choice).  For 16 < nx + nu <= 64 (one wavefront per instance): 6 = wavestream (state in HBM, any
      * N), 7 = waveres (state in registers/LDS, N <= 50; the auto choice below 4 096 instances), 8 = tile48 (nx = 32, nu = 16,
-     * N <= 50, exact arithmetic, fp32 storage: sixteen instances per workgroup as the columns of 16x16 MFMA tiles, duals in LDS;
+     * N <= 50, fp32 storage: sixteen instances per workgroup as the columns of 16x16 MFMA tiles, duals in LDS;
      * the auto choice from 4 096 instances on).  All of them compute identical results. */
     int tiny_batch_set_row_kernel(TinyBatch *tb, int family);
     /* Storage precision of the per-instance horizon arrays (the twelve work arrays, Xref, bounds) in HBM:

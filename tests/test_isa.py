@@ -141,7 +141,8 @@ SCRATCH_PINS = {
     ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb1EEE"): 136,
     ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb0EEE"): 48,
     # the nx = 32 tile kernel keeps no state in registers (duals in LDS, slack streamed): nothing may spill
-    ("admm_tile48.hip", "admm_tile48_kernel"): 0,
+    ("admm_tile48.hip", "admm_tile48_kernelILb1EEE"): 0,
+    ("admm_tile48.hip", "admm_tile48_kernelILb0EEE"): 0,
     ("admm_waveres.hip", "admm_waveres_kernelILi32ELi16ELb1EEE"): 0,   # gains loaded per sweep since round 3
     ("admm_waveres.hip", "admm_waveres_kernelILi32ELi16ELb0EEE"): 0,
 }

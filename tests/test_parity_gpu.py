@@ -1083,7 +1083,7 @@ def test_wave_kernel_vs_oracle(tinympc, oracle_mod, B, wave_kernel):
                 sol.select_kernel(3)  # fma arithmetic for this class: the state-on-chip wave kernel or the streaming kernel
         else:
             sol.select_kernel(3)
-            assert sol.kernel_name() == "waveres<32,16,fast>", sol.kernel_name()
+            assert sol.kernel_name() == ("waveres<32,16,fast>" if wave_kernel == "waveres" else "tile48<32,16,50,fast>"), sol.kernel_name()
         sol.select_kernel(1)          # the streaming MFMA kernel takes over the same workspace
         assert sol.kernel_name() == "stream<8,4>"
         got = sol.get_state()
@@ -1140,13 +1140,15 @@ def test_tile48_kernel_equals_wave_kernel_bitwise(tinympc, N):
             sol.close()
 
 
-@pytest.mark.parametrize("dims", [(32, 16, 50), (16, 8, 49), (16, 4, 33), (20, 8, 21)])
+@pytest.mark.parametrize("dims", [(32, 16, 50), (16, 8, 49), (16, 4, 33), (20, 8, 21), (32, 16, 50, "tile48"), (32, 16, 31, "tile48")])
 def test_wave_kernel_fma_arithmetic(tinympc, oracle_mod, dims):
-    """fma arithmetic of the state-on-chip wave kernel (waveres<...,fast>): held to the bar of every other fma variant —
+    """fma arithmetic of the state-on-chip wave kernel (waveres<...,fast>) and of the matrix-core tile kernel of the nx = 32 class
+    (tile48<...,fast>: every stage one fma chain on the matrix cores): held to the bar of every other fma variant —
     iteration counts and arrays within the reference's own fp64-vs-fp32 spread (compare_states) — over a warm-started
     chain, with the early exit and with a fixed iteration count."""
     O, pr = oracle_mod, tinympc.problems
-    nx, nu, N = dims
+    tile = len(dims) == 4
+    nx, nu, N = dims[:3]
     prob = pr.random_system(nx, nu, N)
     B = 96
     rng = np.random.default_rng(nx + N)
@@ -1158,6 +1160,9 @@ def test_wave_kernel_fma_arithmetic(tinympc, oracle_mod, dims):
         sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
         sol.select_kernel(3)
         assert sol.kernel_name() == f"waveres<{nx},{nu},fast>", sol.kernel_name()
+        if tile:
+            sol.set_row_kernel(8)
+            assert sol.kernel_name() == f"tile48<{nx},{nu},{N},fast>", sol.kernel_name()
         sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
         orc = O.Oracle(prob, np.float32, settings, allow_unpinned_dims=True)
         st = O.new_state(B, nx, nu, N); st["x"][:, 0] = x0
