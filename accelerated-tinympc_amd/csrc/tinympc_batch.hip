@@ -755,9 +755,17 @@ bool tile16_applies(const TinyBatch *tb)
     return !tb->in_xref.set || tb->in_xref.shared;
 }
 
-// auto: one workgroup of three waves per sixteen instances fills the chip from 4 096 instances on (measured: 3.1 ms for any batch up to
-// 4 096 against 2.2 ms per 2 048 on the one-wave-per-instance kernel; 12.5 against 15.2 ms at 16 384, 40 fixed iterations)
-constexpr int kTile48AutoBatch = 4096;
+// auto between the two state-on-chip kernels of the nx = 32 class, by rounds of the launch (measured on the 256 CUs of an MI355X,
+// bench workload: one round of the wave kernel = 2 048 instances = 5.0 ms, one round of the tile kernel = 4 096 instances = 7.2 ms;
+// 2 048: 5.4 against 7.1 ms, 2 304: 8.9 / 7.1, 4 096: 10.1 / 7.4, 4 352: 13.4 / 14.9, 6 144: 15.0 / 14.4, 16 384: 37.5 / 28.6)
+bool tile48_pays(int batch)
+{
+    static const int n_cu = []() { int dev = 0, n = 256; (void)hipGetDevice(&dev); hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; return n; }();
+    const long slots_w = 8L * n_cu, slots_t = 16L * n_cu; // resident instances: two waves per SIMD / one workgroup of sixteen per CU
+    if (batch <= slots_w) return false;
+    const long rounds_w = (batch + slots_w - 1) / slots_w, rounds_t = (batch + slots_t - 1) / slots_t;
+    return rounds_t * 7.2 <= rounds_w * 5.0 * 0.93; // (the wave kernel's last, partly filled round overlaps the one before)
+}
 
 int row_family(const TinyBatch *tb)
 {
@@ -766,7 +774,7 @@ int row_family(const TinyBatch *tb)
     if (tb->wave_ok)
     {
         if (tb->row_family_forced == 3) return 3;
-        if (tb->tile48_ok && !tb->h16 && (tb->row_family_forced == 7 || (tb->row_family_forced < 0 && tb->batch >= kTile48AutoBatch))) return 7;
+        if (tb->tile48_ok && !tb->h16 && (tb->row_family_forced == 7 || (tb->row_family_forced < 0 && tile48_pays(tb->batch)))) return 7;
         return tb->waveres_ok ? 6 : 3;
     }
     // per-instance bounds: the unrolled register-resident kernel (fp32 storage) and the rolled-loop ones (N <= 64, either storage)

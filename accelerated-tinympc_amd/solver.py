@@ -372,7 +372,7 @@ class TinyBatchSolver:
         """0 auto, 1 rowlane (unrolled), 2 rowloop (rolled, N <= 64), 3 rowstream (state in HBM), 4 quadlane (nx=4, nu=1),
         5 tile16 (16 instances per wave, products on the matrix cores; nx=12, nu=4, instantiated N; the auto choice for launches
         of >= 32768 instances), 6 wavestream / 7 waveres (one wavefront per instance, 16 < nx + nu <= 64), 8 tile48 (nx = 32, nu = 16, N <= 50: sixteen
-        instances per workgroup on the matrix cores; automatic from 4096 instances on)."""
+        instances per workgroup on the matrix cores; automatic for 2049 ... 4096 and from 6145 instances on)."""
         self._check(self.lib.tiny_batch_set_row_kernel(self._h, family))
 
     def set_dispatch(self, mode: int):

@@ -200,9 +200,9 @@ extern "C"
      * a 16x16 MFMA tile, gain x state products on the matrix cores in both arithmetic modes, state in registers/LDS; nx = 12,
      * nu = 4 and an instantiated horizon; on request only; with a per-instance reference array or fp16 storage the handle
      * falls back to the auto choice).  For 16 < nx + nu <= 64 (one wavefront per instance): 6 = wavestream (state in HBM, any
-     * N), 7 = waveres (state in registers/LDS, N <= 50; the auto choice below 4 096 instances), 8 = tile48 (nx = 32, nu = 16,
+     * N), 7 = waveres (state in registers/LDS, N <= 50; the auto choice up to 2 048 and for 4 097 ... 6 144 instances), 8 = tile48 (nx = 32, nu = 16,
      * N <= 50, fp32 storage: sixteen instances per workgroup as the columns of 16x16 MFMA tiles, duals in LDS;
-     * the auto choice from 4 096 instances on).  All of them compute identical results. */
+     * the auto choice for 2 049 ... 4 096 and from 6 145 instances on (rounds of the launch)).  All of them compute identical results. */
     int tiny_batch_set_row_kernel(TinyBatch *tb, int family);
     /* Storage precision of the per-instance horizon arrays (the twelve work arrays, Xref, bounds) in HBM:
      * 32 = fp32 like the reference (default); 16 = IEEE binary16 storage with fp32 arithmetic (BASELINE.json

@@ -1103,6 +1103,13 @@ def test_tile48_kernel_equals_wave_kernel_bitwise(tinympc, N):
     nx, nu = 32, 16
     prob = pr.random_system(nx, nu, N)
     shared = pr.bounds_arrays(prob)
+    if N == 50:   # the automatic choice goes by rounds of the launch (256 CUs: 2 048 instances per round of the wave kernel, 4 096 of the tile kernel)
+        for B, name in ((2048, "waveres"), (2049, "tile48"), (4096, "tile48"), (4352, "waveres"), (6144, "waveres"), (6145, "tile48"), (16384, "tile48")):
+            sol = tinympc.TinyBatchSolver(prob, B)
+            assert sol.kernel_name().startswith(name), (B, sol.kernel_name())
+            sol.select_kernel(3)
+            assert sol.kernel_name().startswith(name) and sol.kernel_name().endswith("fast>"), (B, sol.kernel_name())
+            sol.close()
     for B, settings, per_inst, window in ((4096, dict(max_iter=30), False, False), (1000, dict(max_iter=100, abs_pri_tol=3e-2, abs_dua_tol=3e-2), True, False),
                                          (37, dict(max_iter=60, check_termination=7, abs_pri_tol=3e-2, abs_dua_tol=3e-2), False, True), (16, dict(max_iter=1), True, True)):
         s = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1, en_state_bound=1, en_input_bound=1); s.update(settings)
