@@ -1051,7 +1051,7 @@ def test_device_pointer_io_equals_host_io(tinympc):
 def test_wave_kernel_vs_oracle(tinympc, oracle_mod, B, wave_kernel):
     """nx = 32, nu = 16, N = 50 (BASELINE.json configs[3]) on the two wave-per-instance exact kernels (state streamed through
     HBM / state in registers and LDS, the default for N <= 50 below 4 096 instances) and on the sixteen-instances-per-workgroup
-    matrix-core kernel (the default from 4 096 instances on): bitwise equal to the
+    matrix-core kernel (the default wherever its rounds of 4 096 instances beat the wave kernel's of 2 048): bitwise equal to the
     oracle (== the compiled reference for this class, tests/test_oracle.py) over a warm-started chain, with early exit,
     sparse termination checks, one iteration, bounds disabled and a random time-varying reference."""
     O, pr = oracle_mod, tinympc.problems
@@ -1098,7 +1098,7 @@ def test_tile48_kernel_equals_wave_kernel_bitwise(tinympc, N):
     array) against the one-wave-per-instance kernel it replaces for large batches: every work array, residuals, iteration counts
     and status bit for bit — ragged batches (columns past the batch), per-instance bounds, window of a trajectory table as the
     reference, warm-started chains in which the columns of a tile converge at different iterations, sparse termination checks,
-    horizons below the capacity of 50; and the automatic choice from 4 096 instances on."""
+    horizons below the capacity of 50; and the automatic choice (by rounds of the launch)."""
     pr = tinympc.problems
     nx, nu = 32, 16
     prob = pr.random_system(nx, nu, N)
