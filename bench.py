@@ -384,6 +384,18 @@ def main():
             fast["_u_fixed10"] = sol.get_u()[:npar].copy()
             sol.set_settings(**settings)
         sol.select_kernel(0)
+    elif rank == 0 and world == 1 and not args.kernel and args.config == "random32" and sol.kernel_name().startswith(("tile48", "waveres")):
+        sol.select_kernel(3)   # the nx = 32 class: kernel time of the fma instantiation only (its parity bar is held by the GPU tests)
+        step()
+        ms = []
+        for _ in range(min(args.steps, 5)):
+            step()
+            ms.append(sol.last_solve_ms())
+        itf, stf, _ = sol.get_status()
+        fast = dict(kernel=sol.kernel_name(), kernel_ms=float(np.mean(ms)), solves_per_s=B / (float(np.mean(ms)) * 1e-3),
+                    f32_frac=cost.flops_of(itf, stf) / (float(np.mean(ms)) * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                    mean_iters=float(itf.mean()), note="kernel time only; parity bar = the reference's own fp64/fp32 spread (tests/test_parity_gpu.py::test_wave_kernel_fma_arithmetic)")
+        sol.select_kernel(0)
 
     # warm-started closed loop (how the reference's examples actually run the solver, quadrotor_tracking.cpp:93-118):
     # every MPC step = dual reset + solve + plant step + window slide, all `ksteps` of them inside one kernel launch with
