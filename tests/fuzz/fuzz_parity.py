@@ -34,6 +34,8 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 CLASSES = [("quad", 30), ("quad", 25), ("quad", 20), ("quad", 10), ("quad", 17), ("quad", 7), ("quad", 36), ("quad", 40), ("quad", 50), ("quad", 61), ("quad", 67), ("cartpole", 10),
            ("cartpole", 23), ("odd", 7), ("odd", 13), ("rand32", 50), ("rand32", 50), ("rand32", 23), ("rand32", 2), ("r8_4", 9), ("r12_2", 14), ("r4_2", 8), ("r4_4", 35), ("w16_8", 10), ("w16_4", 12), ("w20_8", 11), ("w24_4", 9)]
+if len(sys.argv) > 3:   # optional third argument: only the classes whose name contains it (e.g. "rand32": the nx = 32 kernels incl. tile48)
+    CLASSES = [c for c in CLASSES if sys.argv[3] in c[0]]
 t_end, rounds, solves, t_note, overflowed, refused = time.time() + budget, 0, 0, time.time(), 0, 0
 while time.time() < t_end:
     if time.time() - t_note > 30:
