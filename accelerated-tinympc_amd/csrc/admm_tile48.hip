@@ -1,5 +1,7 @@
 // admm_tile48.hip — the nx = 32, nu = 16 class (BASELINE.json configs[3]) with SIXTEEN INSTANCES PER WORKGROUP as the columns of
 // 16 x 16 matrix-core tiles: the design of admm_tile16.hip for a stacked vector of 48 rows.
+// Restates tiny_solve() (src/tinympc/admm.cpp:111-152) with its six step functions fused (forward_pass :27-37, update_slack :45-61,
+// update_dual :67-71, update_linear_cost :77-85, termination_condition :91-109, backward_pass_grad :15-22), like the other kernels.
 //
 // admm_waveres.hip gives an instance one wave and is bound by vector-instruction issue: every product is a v_mul_f32 and every
 // sum a v_add_f32 of one row of one instance per lane (296 vector instructions per instance and horizon step pair).  Here
