@@ -135,6 +135,16 @@ __global__ void zero_kernel(float *__restrict__ dst, int layout, Geo g, int fam,
     }
 }
 
+// the duals pair g | y between fp32 and binary16 (tiny_batch_set_storage(tb, 16) is a preference: the width follows the kernel a call resolves to)
+__global__ void dual_width_kernel(const float *__restrict__ src, float *__restrict__ dst, long long n, int to32)
+{
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+    {
+        if (to32) dst[e] = (float)reinterpret_cast<const _Float16 *>(src)[e];
+        else reinterpret_cast<_Float16 *>(dst)[e] = (_Float16)src[e]; // round to nearest even, like every store of the 16-bit mode
+    }
+}
+
 // x0 <- Adyn*x0 + Bdyn*u.col(0)   (quadrotor_hovering.cpp:110-111), and x.col(0) <- x0 (:95).
 // One thread per instance; matrices column-major in global memory (tiny, cache resident).
 // Summation order = Eigen's for that expression (pinned bit for bit against that expression compiled from the reference, tests/test_oracle.py:
@@ -290,7 +300,9 @@ struct TinyBatch
     int last_dispatch = 0;        // what the most recent solve launch did: 0 index order, 1 predicted longest first, 2 the caller's order
     bool closed_loop_run = false; // inside tiny_batch_mpc_run_*(steps > 1): the auto choice keeps the kernel with the on-chip loop
     bool h16 = false; // ROW-layout arrays, Xref and bounds stored as IEEE binary16 (tiny_batch_set_storage)
-    bool dual32 = false; // with h16: the duals pair gy stays fp32 (tiny_batch_set_storage_ex)
+    bool dual32 = false; // with h16: the duals pair gy IS fp32 right now (the state of the array)
+    bool dual32_pref = false;   // tiny_batch_set_storage(tb, 16): fp32 duals wherever the kernel a call resolves to implements them, 16-bit duals elsewhere
+    bool dual32_forced = false; // tiny_batch_set_storage_ex(tb, 16, 32): fp32 duals or TINY_BATCH_EUNSUPPORTED
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -718,6 +730,31 @@ int prepare_inputs(TinyBatch *tb, int layout)
 int row_family(const TinyBatch *tb);
 constexpr int kTile16AutoBatch = 32768;
 
+// fp16 storage: bring the duals pair to the width the coming launch implements.  Under tiny_batch_set_storage(tb, 16) fp32 duals are a
+// PREFERENCE (the register-resident 16-lane and quad kernels keep them, every other kernel — streamed state, per-instance bounds under
+// fp16, the optional terms, the six single-function kernels — stores binary16 duals): the array is converted in place of being refused.
+// An explicit tiny_batch_set_storage_ex(tb, 16, 32) stays a requirement (the caller is told when a kernel cannot honour it).
+int settle_dual_width(TinyBatch *tb, bool kernel_keeps_fp32_duals)
+{
+    if (!tb->h16 || tb->dual32_forced) return 0;
+    const bool want32 = tb->dual32_pref && kernel_keeps_fp32_duals;
+    if (tb->dual32 == want32) return 0;
+    if (tb->layout == LAYOUT_ROW && tb->pair[5])
+    {
+        float *nw = nullptr;
+        TRY(dev_alloc_zero(&nw, want32 ? tb->pair_floats : (tb->pair_floats + 1) / 2));
+        hipLaunchKernelGGL(dual_width_kernel, dim3(grid_for((long long)tb->pair_floats)), dim3(256), 0, tb->stream, tb->pair[5], nw, (long long)tb->pair_floats, want32 ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(tb->stream));
+        (void)hipFree(tb->pair[5]);
+        tb->pair[5] = nw;
+    }
+    tb->dual32 = want32;
+    invalidate_graph(tb); // the array pointer is a kernel argument
+    return 0;
+}
+bool family_keeps_fp32_duals(int fam) { return fam == 0 || fam == 4; }
+
 int resolve_variant(TinyBatch *tb, int *out)
 {
     int v = tb->variant;
@@ -810,7 +847,8 @@ void update_kname(TinyBatch *tb)
     char nm[96];
     const std::string keep = g_err;
     if (resolve_variant(tb, &v)) { tb->kname = "unsupported"; g_err = keep; return; }
-    const char *ar = v == VAR_ROW_EXACT ? "exact" : "fast", *sto = tb->h16 ? (tb->dual32 ? ",h16d" : ",h16") : "";
+    const bool d32 = tb->h16 && (tb->dual32_forced ? tb->dual32 : (tb->dual32_pref && v != VAR_STREAM && family_keeps_fp32_duals(row_family(tb))));
+    const char *ar = v == VAR_ROW_EXACT ? "exact" : "fast", *sto = tb->h16 ? (d32 ? ",h16d" : ",h16") : "";
     if (v == VAR_STREAM) snprintf(nm, sizeof nm, "stream<%d,%d>", tb->NXC, tb->NUC);
     else if (row_family(tb) == 0) snprintf(nm, sizeof nm, "rowlane<%d,%d,%d,%s%s>", tb->nx, tb->nu, tb->N, ar, sto);
     else if (row_family(tb) == 1) snprintf(nm, sizeof nm, "rowloop<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
@@ -863,11 +901,12 @@ int run_step(TinyBatch *tb, int fn, int *converged_host, int *n_true)
         return fail(TINY_BATCH_ENOTREADY, "set_cache, set_dynamics and set_settings must be called first");
     if (!tb->rowmath_ok)
         return fail(TINY_BATCH_EUNSUPPORTED, "the single-function kernels need nx + nu <= 16 and an entry in TINY_FOR_EACH_ROWDIMS (nx=%d nu=%d)", tb->nx, tb->nu);
-    if (tb->dual32) return fail(TINY_BATCH_EUNSUPPORTED, "the single-function kernels do not implement fp16 storage with fp32 duals");
+    if (tb->dual32_forced) return fail(TINY_BATCH_EUNSUPPORTED, "the single-function kernels do not implement fp16 storage with fp32 duals (tiny_batch_set_storage_ex(tb, 16, 32))");
     TRY(check_optional_terms(tb));
     TRY(set_device(tb));
     if (tb->gains_dirty) TRY(pack_gains(tb));
     TRY(ensure_layout(tb, LAYOUT_ROW));
+    TRY(settle_dual_width(tb, false));
     TRY(prepare_inputs(tb, LAYOUT_ROW));
     TRY(flush_pending(tb));
     if (!tb->conv_dev) TRY(dev_alloc_zero((float **)&tb->conv_dev, tb->batch));
@@ -913,6 +952,7 @@ int prepare_solve(TinyBatch *tb, int *variant)
     {
         const int layout = (v == VAR_STREAM) ? LAYOUT_TILE : LAYOUT_ROW;
         TRY(ensure_layout(tb, layout));
+        TRY(settle_dual_width(tb, layout == LAYOUT_ROW && family_keeps_fp32_duals(row_family(tb))));
         TRY(prepare_inputs(tb, layout));
     }
     TRY(flush_x0_zero(tb)); // every solve reads x.col(0)
@@ -1743,7 +1783,10 @@ int tiny_batch_set_storage(TinyBatch *tb, int bits)
 {
     CHECK_TB(tb);
     const bool d32 = bits == 16 && (tb->row_dims_ok || tb->quad_ok);
-    return tiny_batch_set_storage_ex(tb, bits, d32 ? 32 : bits);
+    TRY(tiny_batch_set_storage_ex(tb, bits, d32 ? 32 : bits));
+    tb->dual32_pref = d32;     // a preference: every solve / step call settles the width on the kernel it resolves to (settle_dual_width)
+    tb->dual32_forced = false;
+    return 0;
 }
 
 int tiny_batch_set_storage_ex(TinyBatch *tb, int bits, int dual_bits)
@@ -1752,6 +1795,8 @@ int tiny_batch_set_storage_ex(TinyBatch *tb, int bits, int dual_bits)
     if (bits != 16 && bits != 32) return fail(TINY_BATCH_EINVAL, "storage must be 32 (fp32, default) or 16 (IEEE binary16)");
     if (dual_bits != bits && !(bits == 16 && dual_bits == 32)) return fail(TINY_BATCH_EINVAL, "dual storage must equal the storage, or be 32 with 16-bit storage");
     const bool want = bits == 16, want_d32 = want && dual_bits == 32;
+    tb->dual32_pref = false;
+    tb->dual32_forced = want_d32;
     if (want == tb->h16 && want_d32 == tb->dual32) return 0;
     if (want_d32 && !(tb->row_dims_ok || tb->quad_ok))
         return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage with fp32 duals needs a register-resident kernel instantiation (nx=%d nu=%d N=%d has none)", tb->nx, tb->nu, tb->N);

@@ -209,9 +209,13 @@ extern "C"
      * configs[4]): every assignment to a work array rounds to nearest even, products, sums and the four residual
      * reductions stay fp32.  Row kernels only (nx + nu <= 16, batch-shared bounds).  Host-side arrays stay float; values
      * are rounded when they are stored.  Changing the precision restarts the workspace from zero, like create.
-     * With bits = 16 the DUALS y, g stay fp32 where the class has a register-resident kernel instantiation (= set_storage_ex(tb,
-     * 16, 32): "fp16 states with fp32 residual accumulation" — with 16-bit duals part of a batch stalls short of the tolerances,
-     * see below); classes without one get 16-bit duals.  tiny_batch_set_storage_ex(tb, 16, 16) forces binary16 everywhere. */
+     * With bits = 16 the DUALS y, g stay fp32 wherever the kernel a call resolves to keeps them ("fp16 states with fp32 residual
+     * accumulation": the register-resident 16-lane and quad kernels — with 16-bit duals part of a batch stalls short of the tolerances,
+     * see below).  That is a PREFERENCE (round 4): a solve or step call that resolves to another kernel — per-instance bounds under
+     * fp16, the optional terms, a forced rolled / streaming row kernel, the six single-function calls — converts the duals pair to
+     * binary16 (rounding to nearest even) and runs, and converts back when a later call resolves to a kernel with fp32 duals;
+     * tiny_batch_kernel_name() says which (",h16d" / ",h16").  tiny_batch_set_storage_ex(tb, 16, 16) forces binary16 everywhere,
+     * tiny_batch_set_storage_ex(tb, 16, 32) makes fp32 duals a requirement. */
     int tiny_batch_set_storage(TinyBatch *tb, int bits);
     /* The same with the precision of the DUALS y, g chosen separately: (32, 32) and (16, 16) are tiny_batch_set_storage;
      * (16, 32) keeps the duals — the running sums of the primal residuals, admm.cpp:69-70 — in fp32 while the other ten

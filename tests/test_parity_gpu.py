@@ -2052,6 +2052,82 @@ def test_default_16_bit_storage_keeps_the_duals_in_fp32_where_a_register_residen
         sol.close()
 
 
+def test_default_16_bit_storage_is_a_preference_not_a_refusal(tinympc, oracle_mod):
+    """tiny_batch_set_storage(tb, 16) asks for fp32 duals where the kernel keeps them and must not make anything fail that the 16-bit
+    mode could do (round-3 advisor finding): per-instance bounds, the Uref term, a forced rolled kernel and the single-function calls
+    resolve to kernels with binary16 duals — the duals pair is converted and the result is the `_h16` oracle's, bit for bit; a later
+    call that resolves to the register-resident kernel gets fp32 duals back (`_h16d` oracle); an explicit (16, 32) stays a requirement."""
+    O, pr = oracle_mod, tinympc.problems
+    prob = pr.quadrotor(20, 30)
+    nx, nu, N, B = 12, 4, 30, 37
+    rng = np.random.default_rng(5)
+    x0 = rng.uniform(-0.3, 0.3, size=(B, nx)).astype(np.float32)
+    xref = (rng.standard_normal((B, N, nx)) * 0.1).astype(np.float32)
+    shared = pr.bounds_arrays(prob)
+    per_inst = tuple(np.broadcast_to(a, (B,) + a.shape).copy() for a in shared)
+    settings = dict(O.DEFAULT_SETTINGS, max_iter=40)
+    xref_h, x0_h = O.round_h16(xref), O.round_h16(x0)
+
+    def oracle_solve(kind, bnds, n=2):
+        st = O.new_state(B, nx, nu, N)
+        st["x"][:, 0] = x0_h
+        orc = O.Oracle(prob, kind, settings)
+        for _ in range(n):
+            st["y"][:] = 0; st["g"][:] = 0
+            orc.solve(st, *tuple(O.round_h16(b) for b in bnds), xref_h, nthreads=8)
+        return st
+
+    # (a) per-instance bounds under fp16 storage: the streaming row kernel, binary16 duals
+    sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+    sol.set_storage(16)
+    sol.set_bounds(*shared); sol.set_xref(xref); sol.set_x0(x0)
+    assert sol.kernel_name() == "rowlane<12,4,30,exact,h16d>", sol.kernel_name()
+    sol.set_bounds(*per_inst)
+    assert sol.kernel_name().endswith(",h16>") and not sol.kernel_name().startswith("rowlane"), sol.kernel_name()
+    for _ in range(2):
+        sol.reset_dual_variables(); sol.solve()
+    assert_bitwise(sol.get_state(), oracle_solve("h16", shared), "set_storage(16) + per-instance bounds")
+    # (b) back to shared bounds: the register-resident kernel, fp32 duals again (the state carries over, converted)
+    sol.set_bounds(*shared)
+    assert sol.kernel_name() == "rowlane<12,4,30,exact,h16d>", sol.kernel_name()
+    sol.reset_workspace(); sol.set_x0(x0)
+    for _ in range(2):
+        sol.reset_dual_variables(); sol.solve()
+    assert_bitwise(sol.get_state(), oracle_solve("h16d", shared), "set_storage(16), shared bounds again")
+    # (c) a forced rolled kernel and (d) a single-function call
+    sol.set_row_kernel(2)
+    assert sol.kernel_name() == "rowloop<12,4,exact,h16>", sol.kernel_name()
+    sol.reset_workspace(); sol.set_x0(x0)
+    for _ in range(2):
+        sol.reset_dual_variables(); sol.solve()
+    want = oracle_solve("h16", shared)
+    assert_bitwise(sol.get_state(), want, "set_storage(16) + forced rowloop")
+    sol.set_row_kernel(0)
+    sol.forward_pass()  # the single-function kernels store binary16 duals: converted, not refused
+    orc = O.Oracle(prob, "h16", settings)
+    orc.step("forward_pass", want, *tuple(O.round_h16(b) for b in shared), xref_h)
+    got = sol.get_state()
+    for name in ("x", "u", "y", "g"):
+        assert got[name].tobytes() == want[name].tobytes(), name
+    sol.close()
+    # (e) the Uref term
+    sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+    sol.set_storage(16)
+    sol.set_bounds(*shared); sol.set_xref(xref); sol.set_x0(x0)
+    uref = (rng.standard_normal((B, N - 1, nu)) * 0.05).astype(np.float32)
+    sol.set_input_cost(prob["R"]); sol.set_uref(uref); sol.set_optional_terms(True, False)
+    assert sol.kernel_name() == "rowstream<12,4,exact,h16>", sol.kernel_name()
+    sol.reset_dual_variables(); assert sol.solve() in (0, 1)
+    sol.close()
+    # (f) an explicit (16, 32) is still a requirement
+    sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+    sol.set_storage(16, 32)
+    sol.set_bounds(*per_inst); sol.set_xref(xref); sol.set_x0(x0)
+    with pytest.raises(tinympc.TinyBatchError):
+        sol.solve()
+    sol.close()
+
+
 def test_per_instance_bounds_stay_on_the_register_resident_kernel_and_cost_little(tinympc):
     """The headline workload with every instance owning its bounds (the same values, so the iterates are identical): the
     handle stays on rowlane<12,4,30,exact>, results equal the shared-bounds run bit for bit, kernel time within 25 % of it
