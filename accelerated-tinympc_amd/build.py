@@ -98,5 +98,66 @@ def device_asm(source: str) -> Path:
     return out
 
 
+# kernel family (the name tiny_batch_kernel_name() reports, up to the '<') -> the translation unit that holds its device code
+KERNEL_SOURCES = {"rowlane": "admm_rowlane.hip", "rowloop": "admm_rowloop.hip", "rowstream": "admm_steps.hip", "quadlane": "admm_quadlane.hip",
+                  "tile16": "admm_tile16.hip", "tile48": "admm_tile48.hip", "waveres": "admm_waveres.hip", "wavestream": "admm_wave.hip",
+                  "stream": "admm_stream.hip", "rows64": "tinympc_batch64.hip", "thread64": "tinympc_batch64.hip"}
+
+
+def _elf_sections(b: bytes, base: int = 0) -> dict:
+    import struct
+    assert b[base:base + 4] == b"\x7fELF", "not an ELF image"
+    shoff = struct.unpack_from("<Q", b, base + 0x28)[0]
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, base + 0x3A)
+    secs = [struct.unpack_from("<IIQQQQ", b, base + shoff + i * shentsize) for i in range(shnum)]
+    stro = base + secs[shstrndx][4]
+    out = {}
+    for name, typ, _flags, _addr, off, size in secs:
+        out[b[stro + name:b.index(b"\0", stro + name)].decode()] = (base + off, size, typ)
+    return out
+
+
+def device_isa_sha(source: str) -> str:
+    """sha256 (16 hex digits) over the gfx950 machine code (.text) and kernel descriptors (.rodata) of one translation unit, read from
+    the object file build() left in lib/ — the clang offload bundle inside its .hip_fatbin section, parsed here (no tool is executed:
+    bench.py calls this with the GPU initialised).  It binds a measured figure (profiles/hbm_traffic.json) to the CODE it was taken
+    on: unlike a hash of the source text it does not move when a comment does."""
+    import hashlib
+    import struct
+    obj = PKG / "lib" / (Path(source).stem + ".o")
+    b = obj.read_bytes()
+    off, size, _ = _elf_sections(b)[".hip_fatbin"]
+    fb = b[off:off + size]
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    assert fb.startswith(magic), "uncompressed clang offload bundle expected"
+    n = struct.unpack_from("<Q", fb, len(magic))[0]
+    p = len(magic) + 8
+    h = hashlib.sha256()
+    found = False
+    for _ in range(n):
+        eo, es, ts = struct.unpack_from("<QQQ", fb, p)
+        p += 24
+        triple = fb[p:p + ts].decode()
+        p += ts
+        if "gfx950" in triple and es:
+            found = True
+            secs = _elf_sections(fb, eo)
+            for name in (".text", ".rodata"):
+                if name in secs and secs[name][2] != 8:  # (8 = SHT_NOBITS)
+                    o, sz, _ = secs[name]
+                    h.update(fb[o:o + sz])
+    assert found, f"no gfx950 code object in {obj}"
+    return h.hexdigest()[:16]
+
+
+def kernel_isa_sha(kernel_name: str) -> str | None:
+    """device_isa_sha of the translation unit behind a kernel name such as 'tile16<12,4,30,exact>'; None for an unknown family or a missing object."""
+    src = KERNEL_SOURCES.get(kernel_name.split("<", 1)[0])
+    try:
+        return device_isa_sha(src) if src else None
+    except (OSError, AssertionError, KeyError):
+        return None
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

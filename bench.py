@@ -73,6 +73,42 @@ def kernel_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
+def kernel_isa_sha(kernel_name: str):
+    """Hash of the gfx950 machine code of the translation unit behind `kernel_name` (accelerated-tinympc_amd/build.py: read from the
+    object file, nothing is executed).  profiles/hbm_traffic.json binds a PMC figure to it: the figure survives a comment edit and
+    goes stale exactly when the kernel's code changes."""
+    import accelerated_tinympc_amd as T
+    return T.build.kernel_isa_sha(kernel_name)
+
+
+def cpu_all_cores(config: str, total: int, settings: dict, seconds: float = 5.0):
+    """`cpu_baseline.all_cores`: the COMPILED REFERENCE on every host core this job may use — one process per core, because the
+    reference keeps its solver in process-global objects (tiny_wrapper.cpp; oracle/ref_shim.cpp likewise) — each timing cold-start
+    tiny_solve() calls over its own slice of the benchmarked workload (oracle/ref_worker.py).  Called BEFORE this process touches
+    the GPU: a process that has initialised HIP must not start other programs on this pool."""
+    import subprocess
+    ncores = usable_cores()
+    count = 2048 if config == "tracking" else 32
+    go_at = time.time() + 8.0  # imports + workload generation of the slowest worker
+    cmd = [sys.executable, str(ROOT / "oracle" / "ref_worker.py"), "--config", config, "--total", str(total), "--count", str(count),
+           "--seconds", str(seconds), "--settings", json.dumps(settings), "--go-at", repr(go_at)]
+    procs = [subprocess.Popen(cmd + ["--start", str((k * count) % max(1, total - count + 1))], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for k in range(ncores)]
+    outs = []
+    for pr_ in procs:
+        so, se = pr_.communicate(timeout=120)
+        if pr_.returncode != 0:
+            return {"error": (se or "").strip().splitlines()[-1:] or ["worker failed"]}
+        outs.append(json.loads(so.strip().splitlines()[-1]))
+    n = sum(o["solves"] for o in outs)
+    t = max(o["seconds"] for o in outs)
+    return dict(value=n / t, unit="solves/s", cores=ncores, kind=outs[0]["kind"], processes=ncores, cpu_model=cpu_model(),
+                per_core=[o["solves"] / o["seconds"] for o in outs],
+                sample=f"{n} cold-start tiny_solve calls, {ncores} processes x {count}-instance passes of the same workload for {t:.1f} s each, "
+                       f"mean {float(np.mean([o['mean_iters'] for o in outs])):.1f} iterations, FTZ/DAZ off",
+                build="g++ -O3, SSE2 (x86-64 baseline): the parity build of the reference, one process per core (its solver is a process-global object)")
+
+
 def cpu_model() -> str:
     try:
         for l in open("/proc/cpuinfo"):
@@ -152,7 +188,8 @@ def cpu_baseline(prob, make_batch, settings, seconds_target=12.0, fixed10_n=0):
     port = O.Oracle(prob, np.float32, settings)
     nbp, tp, _, _ = timed(port, ncores, 4.0, max(64, min(4096, chunk)) * ncores)
     out["port_all_cores"] = dict(value=nbp / tp, unit="solves/s", cores=ncores, kind="port", cpu_model=cpu_model(),
-                                 sample=f"{nbp} solves, OpenMP over instances, {tp:.1f} s", build="gcc -O3 -march=native -fopenmp (oracle/Makefile)")
+                                 sample=f"{nbp} solves, OpenMP over instances, {tp:.1f} s", build="gcc -O3 -ffp-contract=off -fopenmp, no -march=native (oracle/Makefile); the bit-exact-order C port, "
+                                       "4x slower per core than the compiled reference: a labelled extra, not the CPU baseline")
     # the same first instances at a FIXED iteration count (tolerances 0, 10 iterations): the checker's side of the fma-mode
     # parity figure (SURVEY.md section 7 "Parity definition" (i)); not timed
     if fixed10_n:
@@ -241,6 +278,19 @@ def main():
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 as\n  python -m torch.distributed.run --nnodes=1 "
                          f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...\n")
         raise SystemExit(2)
+
+    # the all-core CPU baseline runs first: it starts one reference process per core, which this process may only do while it has
+    # not yet initialised the GPU
+    all_cores = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cfg0 = CONFIGS[args.config]
+        try:
+            all_cores = cpu_all_cores(args.config, (args.batch or cfg0.get("per_gpu") or cfg0["total"]),
+                                      dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1, en_state_bound=1, en_input_bound=1)
+                                      if args.mode == "early_exit" else
+                                      dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=10, check_termination=1, en_state_bound=1, en_input_bound=1))
+        except Exception as e:  # noqa: BLE001
+            all_cores = {"error": f"{type(e).__name__}: {e}"}
 
     import torch
     import accelerated_tinympc_amd as T
@@ -361,6 +411,54 @@ def main():
     total_solves = total * args.steps
     value = total_solves / dt
     extras_ok = rank == 0 and world == 1 and not args.kernel and args.config == "tracking"
+    # "report both fixed-iteration (tol = 0, max_iter = 10) and early-exit throughput" — the same kernel, exact
+    # arithmetic, same inputs, ten iterations for every instance; and the H2D / D2H legs of a host-driven step (x0 up, u.col(0) down),
+    # hipEvent-timed on pinned buffers.  Extras of rank 0: neither enters `value`.
+    fixed10 = transfers = None
+    if rank == 0 and world == 1 and args.mode == "early_exit":
+        try:
+            sol.set_settings(**dict(settings, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=10))
+            for _ in range(2):
+                step()
+            sol.synchronize()
+            torch.cuda.synchronize()
+            nst = max(5, min(args.steps, 20))
+            t_f = time.perf_counter()
+            for _ in range(nst):
+                step()
+            sol.synchronize()
+            dt_f = time.perf_counter() - t_f
+            ms_f = []
+            for _ in range(5):
+                step()
+                ms_f.append(sol.last_solve_ms())
+            it10, st10, _ = sol.get_status()
+            fixed10 = {"solves_per_s": B * nst / dt_f, "ms_per_step": dt_f / nst * 1e3, "kernel": sol.kernel_name(), "kernel_ms": float(np.mean(ms_f)),
+                       "iterations": int(it10.max()), "f32_frac": cost.flops_of(it10, st10) / (float(np.mean(ms_f)) * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                       "note": "tolerances 0, max_iter 10 (SURVEY.md section 8(d) config 2/3 'fixed-iteration'), exact arithmetic, wall time of the steps"}
+        except Exception as e:  # noqa: BLE001
+            fixed10 = {"error": f"{type(e).__name__}: {e}"}
+        sol.set_settings(**settings)
+        try:
+            h_x0 = torch.from_numpy(np.ascontiguousarray(x0)).pin_memory()
+            d_u0t = torch.zeros((B, NU), dtype=torch.float32, device="cuda")
+            h_u0 = torch.empty((B, NU), dtype=torch.float32).pin_memory()
+            sol._check(lib.tiny_batch_get_u0_device(h, C.c_void_p(d_u0t.data_ptr())))
+            sol.synchronize()
+            up, down = [], []
+            for _ in range(12):
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record(); d_x0.copy_(h_x0, non_blocking=True); e1.record(); h_u0.copy_(d_u0t, non_blocking=True); e2.record()
+                torch.cuda.synchronize()
+                up.append(e0.elapsed_time(e1)); down.append(e1.elapsed_time(e2))
+            up, down = float(np.median(up[2:])), float(np.median(down[2:]))
+            transfers = {"h2d_ms": up, "h2d_bytes": int(h_x0.numel() * 4), "h2d_GBs": h_x0.numel() * 4 / (up * 1e-3) / 1e9,
+                         "d2h_ms": down, "d2h_bytes": int(h_u0.numel() * 4), "d2h_GBs": h_u0.numel() * 4 / (down * 1e-3) / 1e9,
+                         "pcie_inclusive_solves_per_s": B / (dt / args.steps + (up + down) * 1e-3),
+                         "note": "x0 of the batch up, u.col(0) down, pinned host buffers, hipEvent pairs on the copy stream, median of 10; the timed "
+                                 "region keeps its inputs resident in HBM, so neither leg is part of `value`"}
+        except Exception as e:  # noqa: BLE001
+            transfers = {"error": f"{type(e).__name__}: {e}"}
     # the opt-in fma-chain arithmetic of the same kernel, for reference (not the headline: see DESIGN.md §3)
     fast = None
     if extras_ok and sol.kernel_name().startswith(("rowlane", "tile16")):
@@ -502,10 +600,14 @@ def main():
             try:
                 ent = json.loads(tf.read_text()).get(f"{sol.kernel_name()}:{args.mode}:{B}")
                 if isinstance(ent, dict):
-                    if ent.get("csrc_sha") == kernel_source_sha():
+                    isa = kernel_isa_sha(sol.kernel_name())
+                    if ent.get("isa_sha") is not None and ent.get("isa_sha") == isa:
+                        traffic, traffic_note = ent["bytes"], (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated ({ent.get('profile')}); bound to the "
+                                                               f"kernel's device code {isa}")
+                    elif ent.get("isa_sha") is None and ent.get("csrc_sha") == kernel_source_sha():
                         traffic, traffic_note = ent["bytes"], f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated; kernel sources {ent['csrc_sha']}"
                     else:
-                        traffic_note = f"stale: measured on kernel sources {ent.get('csrc_sha')}, this build is {kernel_source_sha()}"
+                        traffic_note = f"stale: measured on device code {ent.get('isa_sha')} (sources {ent.get('csrc_sha')}), this build's kernel is {isa}"
                 elif ent is not None:
                     traffic_note = "stale: figure predates the source binding"
             except Exception:
@@ -551,6 +653,10 @@ def main():
                        "max_iters": agg["max_iters"], "frac_converged": agg["n_converged"] / agg["n_instances"]},
             "roofline": roof,
         }
+        if fixed10 is not None:
+            line["fixed10"] = fixed10
+        if transfers is not None:
+            line["transfers"] = transfers
         if fast is not None:
             line["fast_arithmetic"] = fast
         if gather is not None:
@@ -563,6 +669,8 @@ def main():
             line["fp64_tinytype"] = fp64
         if not args.no_cpu and world == 1:  # rank 0 at N=1 only: the other ranks of a multi-GPU run would sit in the barrier
             cb, ref_first, kind = cpu_baseline(prob, make_batch, settings, fixed10_n=(npar if (fast is not None and "_u_fixed10" in fast) else 0))
+            if all_cores is not None:
+                cb["all_cores"] = all_cores
             line["cpu_baseline"] = cb
             u_scale = max(abs(prob["u_max"]), abs(prob["u_min"]))
             line["parity"] = parity_of(gpu_u, iters, status, ref_first, kind, u_scale)

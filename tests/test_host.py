@@ -236,12 +236,23 @@ def test_native_names_header_is_plain_c_and_matches_the_binding(tinympc, tmp_pat
         assert [f[0] for f in native.TinyWorkspace._fields_[3:]] == ref_members
 
 
-@pytest.mark.parametrize("name", ["r01_bench_default_line.json", "r02_bench_default_line_d.json", "r02_bench_random32_line_b.json"])
+@pytest.mark.parametrize("name", ["r01_bench_default_line.json", "r02_bench_default_line_d.json", "r02_bench_random32_line_b.json",
+                                  "r04_bench_default_line_a.json", "r04_bench_random32_line_a.json"])
 def test_recorded_bench_line_has_the_contract_fields(name):
     """profiles/*_bench_*_line*.json are the stdout of `python bench.py [--config random32]` on the MI355X: the keys the driver reads."""
     import json
     d = json.loads((ROOT / "profiles" / name).read_text())
-    if name.startswith("r02"):   # round 2 made the line self-describing
+    if name.startswith("r04"):   # round 4: what the round-3 review asked the line to carry so that it can be checked without trusting it
+        ac = d["cpu_baseline"]["all_cores"]   # the COMPILED REFERENCE on every usable host core, one process per core
+        assert ac["kind"] == "reference" and ac["cores"] == ac["processes"] == d["cpu_baseline"]["host_cores_usable"] and ac["value"] > d["cpu_baseline"]["value"]
+        assert "march=native" not in d["cpu_baseline"]["port_all_cores"]["build"].replace("no -march=native", "")
+        t = d["transfers"]                     # SURVEY.md section 8(d): H2D / D2H timed separately, never part of `value`
+        assert t["h2d_ms"] > 0 and t["d2h_ms"] > 0 and t["h2d_bytes"] == d["config"]["instances_per_gpu"] * d["config"]["nx"] * 4
+        assert t["pcie_inclusive_solves_per_s"] < d["value"]
+        f = d["fixed10"]                       # fixed-iteration throughput in exact arithmetic next to the early-exit headline
+        assert f["iterations"] == 10 and f["kernel"].endswith("exact>") and f["solves_per_s"] > d["value"]
+        assert d["roofline"]["traffic"] > 0 and "device code" in d["roofline"]["traffic_note"]   # bound to the kernel's ISA, not to the source text
+    if name.startswith(("r02", "r04")):   # round 2 made the line self-describing
         assert d["config"]["world_size_seen"] == d["n_gpus"] and "backend" in d["config"] and d["config"]["instances_total"] > 0
         assert d["parity"]["bitwise_u"] is True and d["parity"]["iter_mismatch"] == 0 and d["parity"]["status_mismatch"] == 0
         kk = d["roofline"]["kernel_ms_per_step"]

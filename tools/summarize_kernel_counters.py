@@ -126,5 +126,7 @@ for w in workloads:
     if line and hbm.get("hbm_bytes_per_launch"):
         tf = prof / "hbm_traffic.json"
         table = json.loads(tf.read_text()) if tf.exists() else {}
-        table[f"{line['kernel']}:early_exit:{line['batch']}"] = {"bytes": hbm["hbm_bytes_per_launch"], "csrc_sha": out["csrc_sha"], "profile": f"{tag}_{w}_counters.json"}
+        import accelerated_tinympc_amd as _T  # the figure is bound to the kernel's DEVICE CODE (build.kernel_isa_sha): a comment edit does not make it stale
+        table[f"{line['kernel']}:early_exit:{line['batch']}"] = {"bytes": hbm["hbm_bytes_per_launch"], "isa_sha": _T.build.kernel_isa_sha(line["kernel"]),
+                                                                   "csrc_sha": out["csrc_sha"], "profile": f"{tag}_{w}_counters.json"}
         tf.write_text(json.dumps(table, indent=1))

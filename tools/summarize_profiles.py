@@ -86,7 +86,7 @@ if line:
     sys.path.insert(0, str(ROOT))
     from bench import kernel_source_sha  # binds the figure to the kernel sources it was measured on (bench.py reports null once they change)
     for k, d in kern.items():
-        table[f"{label(k)}:early_exit:{line['config']['instances_per_gpu']}"] = {"bytes": d["hbm_bytes"], "csrc_sha": kernel_source_sha(), "profile": tag}
+        table[f"{label(k)}:early_exit:{line['config']['instances_per_gpu']}"] = {"bytes": d["hbm_bytes"], "isa_sha": __import__("accelerated_tinympc_amd").build.kernel_isa_sha(label(k)), "csrc_sha": kernel_source_sha(), "profile": tag}
 tf.write_text(json.dumps(table, indent=1))
 print(json.dumps({k: v for k, v in out.items() if k != "bench_line_under_profiler"}, indent=1)[:3000])
 
