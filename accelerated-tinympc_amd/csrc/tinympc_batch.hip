@@ -764,7 +764,15 @@ int resolve_variant(TinyBatch *tb, int *out)
     const bool row_ok = tb->row_dims_ok || tb->rowmath_ok || tb->wave_ok;
     if (tb->variant == VAR_ROW_FAST && tb->wave_ok && row_family(tb) != 6 && row_family(tb) != 7)
         return fail(TINY_BATCH_EUNSUPPORTED, "fma arithmetic for 16 < nx + nu <= 64 needs the state-on-chip wave kernel (N <= 50); beyond that it is the streaming MFMA kernel (variant 1)");
-    if (v == VAR_AUTO) v = row_ok ? VAR_ROW_EXACT : VAR_STREAM;
+    if (v == VAR_AUTO)
+    {
+        // the automatic choice is exact arithmetic or nothing: a class without a compiled exact kernel runs in fma arithmetic on the padded
+        // MFMA kernel only when the caller has asked for it by name (round 4: it used to be selected silently)
+        if (!row_ok)
+            return fail(TINY_BATCH_EUNSUPPORTED, "nx=%d nu=%d has no exact-arithmetic kernel (TINY_FOR_EACH_ROWDIMS / _WAVEDIMS); "
+                                                 "tiny_batch_select_kernel(tb, 1) opts into fma arithmetic on the MFMA streaming kernel", tb->nx, tb->nu);
+        v = VAR_ROW_EXACT;
+    }
     if ((tb->en_uref || tb->en_d2p) && (!tb->rowmath_ok || v == VAR_STREAM))
         return fail(TINY_BATCH_EUNSUPPORTED, "the optional Uref / coeff_d2p terms (tiny_batch_set_optional_terms) are implemented by the row "
                                              "kernels for nx + nu <= 16 only (nx=%d nu=%d, variant %d)", tb->nx, tb->nu, v);
@@ -1760,6 +1768,14 @@ const char *tiny_batch_kernel_name(TinyBatch *tb)
     return tb->kname.c_str();
 }
 
+int tiny_batch_arithmetic(TinyBatch *tb)
+{
+    CHECK_TB(tb);
+    int v = 0;
+    TRY(resolve_variant(tb, &v));
+    return v == VAR_ROW_EXACT ? TINY_BATCH_ARITH_EXACT : TINY_BATCH_ARITH_FMA;
+}
+
 int tiny_batch_set_row_kernel(TinyBatch *tb, int family)
 {
     CHECK_TB(tb);
@@ -1795,14 +1811,14 @@ int tiny_batch_set_storage_ex(TinyBatch *tb, int bits, int dual_bits)
     if (bits != 16 && bits != 32) return fail(TINY_BATCH_EINVAL, "storage must be 32 (fp32, default) or 16 (IEEE binary16)");
     if (dual_bits != bits && !(bits == 16 && dual_bits == 32)) return fail(TINY_BATCH_EINVAL, "dual storage must equal the storage, or be 32 with 16-bit storage");
     const bool want = bits == 16, want_d32 = want && dual_bits == 32;
-    tb->dual32_pref = false;
-    tb->dual32_forced = want_d32;
-    if (want == tb->h16 && want_d32 == tb->dual32) return 0;
     if (want_d32 && !(tb->row_dims_ok || tb->quad_ok))
         return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage with fp32 duals needs a register-resident kernel instantiation (nx=%d nu=%d N=%d has none)", tb->nx, tb->nu, tb->N);
     if (want && !(tb->row_dims_ok || tb->rowmath_ok) )
         return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage is implemented by the row kernels only (nx=%d nu=%d has none)", tb->nx, tb->nu);
     if (want && tb->variant == VAR_STREAM) return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage cannot be combined with the streaming kernel");
+    tb->dual32_pref = false;      // (a refused call leaves the handle as it was)
+    tb->dual32_forced = want_d32;
+    if (want == tb->h16 && want_d32 == tb->dual32) return 0;
     TRY(set_device(tb));
     HIP_TRY(hipStreamSynchronize(tb->stream));
     invalidate_graph(tb);

@@ -74,7 +74,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch_mpc_step_async": [P, C.c_int], "tiny_batch_get_x0": [P, F],
         "tiny_batch_mpc_run_async": [P, C.c_int, C.c_int], "tiny_batch_mpc_run_traj_async": [P, C.c_int, C.c_int, P], "tiny_batch_mpc_run_traj": [P, C.c_int, C.c_int, F],
         "tiny_batch_enable_timing": [P, C.c_int], "tiny_batch_last_solve_ms": [P, F],
-        "tiny_batch_select_kernel": [P, C.c_int], "tiny_batch_set_storage": [P, C.c_int], "tiny_batch_set_storage_ex": [P, C.c_int, C.c_int],
+        "tiny_batch_select_kernel": [P, C.c_int], "tiny_batch_arithmetic": [P], "tiny_batch_set_storage": [P, C.c_int], "tiny_batch_set_storage_ex": [P, C.c_int, C.c_int],
         "tiny_batch_set_row_kernel": [P, C.c_int],
         "tiny_batch_set_dispatch": [P, C.c_int], "tiny_batch_set_dispatch_order_device": [P, P], "tiny_batch_dispatch_applied": [P],
         "tiny_batch_set_optional_terms": [P, C.c_int, C.c_int], "tiny_batch_set_input_cost": [P, F],
@@ -364,6 +364,14 @@ class TinyBatchSolver:
 
     def kernel_name(self) -> str:
         return self.lib.tiny_batch_kernel_name(self._h).decode()
+
+    def arithmetic(self) -> str:
+        """tiny_batch_arithmetic: "exact" (bitwise the reference) or "fma" for what the next solve computes in; raises where no kernel would
+        run (a class without an exact kernel before the caller has opted into fma arithmetic with select_kernel(1))."""
+        rc = self.lib.tiny_batch_arithmetic(self._h)
+        if rc < 0:
+            self._check(rc)
+        return "exact" if rc == 0 else "fma"
 
     def select_kernel(self, variant: int):
         self._check(self.lib.tiny_batch_select_kernel(self._h, variant))

@@ -64,8 +64,11 @@ extern "C"
      * (types.hpp:26-107, quadrotor_hovering.cpp:25-28).
      * Dimensions (glob_opts.hpp:5-7 fixes them at compile time; here they are arguments): any nx <= 64, nu <= 32, N >= 2.
      * Classes with a compiled exact kernel — (nx, nu) = (12,4), (4,1), (8,3), (8,4), (12,2), (4,2), (4,4), (32,16), (16,8),
-     * (16,4), (20,8), (24,4) — compute bitwise what the reference computes; any other class runs in fma arithmetic on the MFMA streaming
-     * kernel (tiny_batch_kernel_name reports "stream<...>").  Beyond those limits: TINY_BATCH_EUNSUPPORTED. */
+     * (16,4), (20,8), (24,4) — compute bitwise what the reference computes.  Any other class has the MFMA streaming kernel in FMA
+     * arithmetic only (results within the reference's own fp64-vs-fp32 spread, not bitwise): the automatic kernel choice never
+     * lands there by itself (round 4) — a solve on such a handle returns TINY_BATCH_EUNSUPPORTED until the caller opts in with
+     * tiny_batch_select_kernel(tb, 1); tiny_batch_arithmetic() says what a solve would compute in.  Beyond those limits create
+     * itself returns TINY_BATCH_EUNSUPPORTED. */
     int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int device);
     void tiny_batch_destroy(TinyBatch *tb);
     /* Launch on this hipStream_t (passed as void*; NULL = the null stream).  Default: NULL. */
@@ -185,6 +188,14 @@ extern "C"
     /* Name of the kernel variant the next solve will launch ("rowlane<12,4,30,exact>", "rowstream<12,4,fast>",
      * "stream<3,1>", with ",h16" appended under fp16 storage). */
     const char *tiny_batch_kernel_name(TinyBatch *tb);
+    /* The ARITHMETIC the next solve computes in — the contract behind the kernel name:
+     *   TINY_BATCH_ARITH_EXACT (0): every product and sum a separately rounded operation in the reference's order: results bitwise
+     *                               equal to the compiled reference (tinytype = float, SSE2 build);
+     *   TINY_BATCH_ARITH_FMA   (1): fused multiply-add chains: within the reference's own fp64-vs-fp32 spread,
+     *                               chosen explicitly (tiny_batch_select_kernel 1 or 3), never by the automatic choice;
+     *   < 0: no kernel would run (TINY_BATCH_EUNSUPPORTED; tiny_batch_last_error() names the opt-in). */
+    enum { TINY_BATCH_ARITH_EXACT = 0, TINY_BATCH_ARITH_FMA = 1 };
+    int tiny_batch_arithmetic(TinyBatch *tb);
     /* Force a kernel variant: 0 = auto (exact arithmetic when the class has an exact kernel — nx + nu <= 16: row
      * kernels, 16 < nx + nu <= 64: wave-per-instance kernel — and the bounds are batch-shared, else streaming),
      * 1 = streaming MFMA kernel (state in HBM, fma arithmetic), 2 = exact arithmetic (bitwise equal to the reference's

@@ -1207,8 +1207,15 @@ def test_classes_without_an_instantiation_run_on_the_padded_mfma_kernel(tinympc,
     for extra in (dict(max_iter=8, abs_pri_tol=0.0, abs_dua_tol=0.0), dict(max_iter=60)):
         settings = dict(O.DEFAULT_SETTINGS, **extra)
         sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
-        assert sol.kernel_name().startswith("stream<"), sol.kernel_name()
         sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
+        # round 4: the arithmetic mode is a contract — the automatic choice is exact arithmetic or nothing, fma arithmetic is an opt-in
+        assert sol.kernel_name() == "unsupported"
+        with pytest.raises(tinympc.TinyBatchError, match="opts into fma"):
+            sol.arithmetic()
+        with pytest.raises(tinympc.TinyBatchError, match="opts into fma"):
+            sol.solve()
+        sol.select_kernel(1)
+        assert sol.kernel_name().startswith("stream<") and sol.arithmetic() == "fma", sol.kernel_name()
         sol.solve()
         got = sol.get_state()
         st = O.new_state(B, nx, nu, N); st["x"][:, 0] = x0
@@ -2049,6 +2056,21 @@ def test_default_16_bit_storage_keeps_the_duals_in_fp32_where_a_register_residen
         assert sol.kernel_name().endswith(want), sol.kernel_name()
         sol.set_storage(16, 16)
         assert sol.kernel_name().endswith(",h16>"), sol.kernel_name()
+        sol.close()
+
+
+def test_arithmetic_mode_is_reported_by_the_library(tinympc):
+    """tiny_batch_arithmetic(): "exact" for every automatic choice (each BASELINE class), "fma" only after the caller selected an fma variant."""
+    pr = tinympc.problems
+    for prob, B in ((pr.quadrotor(20, 30), 64), (pr.quadrotor(20, 30), 40000), (pr.cartpole(10), 64), (pr.random_system(32, 16, 50, seed=1234), 64),
+                    (pr.random_system(32, 16, 50, seed=1234), 4096), (pr.quadrotor(20, 77), 8)):
+        sol = tinympc.TinyBatchSolver(prob, B)
+        sol.set_bounds(*pr.bounds_arrays(prob))
+        assert sol.arithmetic() == "exact" and sol.kernel_name().split(",")[-1].startswith("exact"), sol.kernel_name()
+        sol.select_kernel(3)
+        assert sol.arithmetic() == "fma", sol.kernel_name()
+        sol.select_kernel(0)
+        assert sol.arithmetic() == "exact"
         sol.close()
 
 
