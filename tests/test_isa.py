@@ -141,8 +141,12 @@ SCRATCH_PINS = {
     ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb1EEE"): 136,
     ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb0EEE"): 48,
     # the nx = 32 tile kernel keeps no state in registers (duals in LDS, slack streamed): nothing may spill
-    ("admm_tile48.hip", "admm_tile48_kernelILb1EEE"): 0,
-    ("admm_tile48.hip", "admm_tile48_kernelILb0EEE"): 0,
+    # (round 4: <EXACT, TWO> — TWO is the instantiation for horizons whose duals leave room for a second workgroup per CU: it must also stay
+    #  within 256 registers, which test_tile48_short_horizon_instantiation_fits_two_waves_per_simd checks)
+    ("admm_tile48.hip", "admm_tile48_kernelILb1ELb0EEE"): 0,
+    ("admm_tile48.hip", "admm_tile48_kernelILb0ELb0EEE"): 0,
+    ("admm_tile48.hip", "admm_tile48_kernelILb1ELb1EEE"): 0,
+    ("admm_tile48.hip", "admm_tile48_kernelILb0ELb1EEE"): 0,
     ("admm_waveres.hip", "admm_waveres_kernelILi32ELi16ELb1EEE"): 0,   # gains loaded per sweep since round 3
     ("admm_waveres.hip", "admm_waveres_kernelILi32ELi16ELb0EEE"): 0,
 }
@@ -166,6 +170,16 @@ def test_scratch_sizes_of_the_headline_kernels_are_pinned(listings):
         assert len(sizes) == 1, (src, key, list(sizes))
         (name, got), = sizes.items()
         assert got <= pin, f"{name}: {got} bytes of scratch per lane, pinned at {pin}"
+
+
+def test_tile48_short_horizon_instantiation_fits_two_waves_per_simd(listings):
+    """admm_tile48_kernel<EXACT, TWO = true> serves N <= 24, where two workgroups share a CU (LDS 80 KB each): that only happens while the kernel
+    needs at most 256 registers (round 4: a uniform branch around one store had pushed the exact instantiation to 266 and cost 17 %)."""
+    txt = listings["admm_tile48.hip"]
+    for key in ("admm_tile48_kernelILb1ELb1EEE", "admm_tile48_kernelILb0ELb1EEE"):
+        i = re.search(r"^_Z\w*" + key + r"\w*:", txt, re.M).start()   # the kernel's label; its resource summary follows the body
+        m = re.search(r"; TotalNumVgprs: (\d+)", txt[i:])
+        assert m and int(m.group(1)) <= 256, (key, m and m.group(1))
 
 
 def test_packed_adds_only_where_they_are_deliberate(listings):
