@@ -337,6 +337,20 @@ __device__ __forceinline__ void masked_backward_update(unsigned long long m, flo
                  : "scc");
 }
 
+// closed loop on chip: the lanes in `m` (instances that CONVERGED: the reference returned before v = vnew, admm.cpp:135-142) get their old
+// slack back from the backup, so that the next solve's first sweep finds v | z where every sweep expects the previous slack
+__device__ __forceinline__ void masked_restore_slack(unsigned long long m, const float (&bo)[4], unsigned sn_addr)
+{
+    const f32x4 tv = {acc_get(bo[0]), acc_get(bo[1]), acc_get(bo[2]), acc_get(bo[3])};
+    unsigned long long sx;
+    asm volatile("s_and_saveexec_b64 %[sx], %[m]\n\t"
+                 "ds_write_b128 %[ad], %[tv]\n\t"
+                 "s_mov_b64 exec, %[sx]"
+                 : [sx] "=&s"(sx)
+                 : [m] "s"(m), [ad] "v"(sn_addr), [tv] "v"(tv)
+                 : "memory", "scc");
+}
+
 // [q_i ; r_i] of update_linear_cost (admm.cpp:80-82) for the four rows of a lane: cq - rho * (snew - dual)
 template <bool EXACT>
 __device__ __forceinline__ f32x4 lin_cost4(const f32x4 &cq, const f32x4 &rho4, const f32x4 &t1)
@@ -350,7 +364,10 @@ constexpr int TILE16_MAX_TABLE_ROWS = 512;
 
 // COLD: the launch starts from reset_workspace() (RowParams::cold_start): no live-in array is read (round 3: a separate
 // instantiation — as a run-time branch the two initialisations meet in 270 phi values and the allocator spills)
-template <int N, bool EXACT, bool COLD>
+// MPC: the closed loop on chip (tiny_batch_mpc_run_async): P.mpc_steps solves of every tile inside the launch, the state staying in
+// registers / LDS between them — u_0, the plant step x0 <- Adyn x0 + Bdyn u_0 in the plant kernel's arithmetic, the window slide, the dual
+// reset and the terminal term happen on chip (quadrotor_tracking.cpp:93-118), like admm_rowlane.hip's MPC instantiation
+template <int N, bool EXACT, bool COLD, bool MPC = false>
 __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(const RowParams P)
 {
     constexpr int NX = 12, NU = 4;
@@ -494,6 +511,51 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
     }
     float pN[3] = {0.f, 0.f, 0.f}; // p_{N-1} of the last executed forward sweep
 
+    // backward_pass_grad with the linear cost (admm.cpp:15-22, :80-82) for the lanes in `amask`, the text of the iteration loop's sweep: the closed loop on
+    // chip runs it between two solves for the instances that exhausted max_iter (their last sweep is deferred out of the loop).  (The iteration loop keeps
+    // its own copy: routed through this lambda the warm-start instantiation picks up ten more scratch accesses per iteration.)
+    auto backward_sweep = [&](unsigned long long amask, const float4 *snI, const float4 *tabI, int wsI) {
+        float p[3] = {pN[0], pN[1], pN[2]};
+        // the linear cost of step i - 1 depends on the state only, not on p: it is computed while the products of step i
+        // are in flight
+        auto load_lin = [&](int i, float4 &sl, f32x4 &xr) { // LDS reads of step i's linear cost: issued a step ahead, in front of the MFMAs
+            sl = snI[i * WAVE];
+            xr = load_xref(tabI, wsI, i);
+        };
+        auto make_lin = [&](int i, const float4 &sl, const f32x4 &xr) {
+            const f32x4 sni = {sl.x, sl.y, sl.z, sl.w};
+            return lin_cost4<EXACT>(-(xr * qv), rho4, sni - dual4(i)); // admm.cpp:80-82
+        };
+        float4 sl0; f32x4 xr0;
+        load_lin(N - 2, sl0, xr0);
+        f32x4 lin = make_lin(N - 2, sl0, xr0);
+#pragma unroll
+        for (int i = N - 2; i >= 0; i--)
+        {
+            float4 sl_n = make_float4(0.f, 0.f, 0.f, 0.f); f32x4 xr_n = {0.f, 0.f, 0.f, 0.f};
+            if (EXACT && i > 0) load_lin(i - 1, sl_n, xr_n); // exact: in front of the MFMAs (measured 1.72 -> 1.69 ms; fma: 0.91 -> 0.93 the other way)
+            typename TileMath<EXACT>::InFlight F;
+            M.riccati_issue(p, lin, F);
+            if (!EXACT && i > 0) load_lin(i - 1, sl_n, xr_n);
+#if TINY_T16_SCHED
+            if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
+#endif
+            f32x4 lin_n = lin;
+            if (i > 0) lin_n = make_lin(i - 1, sl_n, xr_n); // in the shadow of the four MFMAs, not behind the sums
+#if TINY_T16_SCHED
+            if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
+#endif
+            float pn[3], dd;
+            M.riccati_finish(F, lin, pn, dd);
+            masked_backward_update(amask, pl[i], dr[i], pn, dd);
+            p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
+            lin = lin_n;
+        }
+    };
+
+    for (int ms = 0;; ++ms) // MPC steps of the closed loop on chip (one pass otherwise)
+    {
+    if (MPC && ms > 0) { st = TINY_STATUS_UNSOLVED_; itn = 1; }
     bool active = valid && (P.max_iter > 0);
     for (int it = 0; it < P.max_iter; ++it)
     {
@@ -617,6 +679,54 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
             }
         }
     }
+    if (!MPC || ms + 1 >= P.mpc_steps) break;
+    // ---------------- advance to the next MPC step (quadrotor_tracking.cpp:101-118): nothing leaves the chip ----------------
+    if constexpr (MPC)
+    {
+        int oz;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+        float4 *const snA = sn + oz;
+        const unsigned sn_addr = (unsigned)(size_t)(lds_float4 *)snA;
+        const bool solved = st == TINY_STATUS_SOLVED_;
+        // [x_0 ; u_0] of the solve that just finished, in the solver's own arithmetic — from the d its last FORWARD sweep used, i.e. before the
+        // deferred backward sweep below replaces it (the live-out's order) —; then the plant step in the plant kernel's
+        // (plant_step_kernel, tinympc_batch.hip: separately rounded products; Adyn x0 through Eigen's GEMV accumulator from +0,
+        // Bdyn u_0 the lazy product's sequential sum — rowlane_math.h plant_step)
+        float un, xn_[3];
+        M.lqr(x0, dr[0], un, xn_);
+        if (P.u0_traj && valid) P.u0_traj[((long long)ms * P.batch + inst) * NU + g] = un;
+        {
+            const f32x16 p0 = TINY_MFMA1(M.A1[0], x0[0], M.negz), p1 = TINY_MFMA1(M.A1[1], x0[1], M.negz), p2 = TINY_MFMA1(M.A1[2], x0[2], M.negz);
+            const f32x16 pb = TINY_MFMA1(M.A2, un, M.negz);
+            f32x4 t[12], t2[4];
+            gather12v(t, p0, p1, p2);
+            gather4v(t2, pb);
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            asm volatile("" : "+v"(z)); // keep the +0 start of the GEMV accumulator: (+0) + (-0) = +0
+            f32x4 acc = z + t[0];
+#pragma unroll
+            for (int k = 1; k < 12; k++) acc = acc + t[k];
+            const f32x4 x1 = acc + reduce4<PLAN_SEQ>(t2);
+            x0[0] = x1[0]; x0[1] = x1[1]; x0[2] = x1[2];
+        }
+        // an instance that exhausted max_iter still owes the backward sweep of its last iteration (deferred out of the loop): its d, p
+        const unsigned long long umask = __ballot(valid && !solved);
+        if (umask != 0ull) backward_sweep(umask, snA, tab + oz, wstart + oz);
+        // v | z of the workspace: the old slack for an instance that converged (the reference returned before v = vnew), the new one otherwise
+        const unsigned long long smask = __ballot(valid && solved);
+#pragma unroll
+        for (int i = 0; i < N; i++) masked_restore_slack(smask, bo[i], sn_addr + i * (WAVE * 16));
+        if (P.xref_mode == 1)
+        {
+            wstart += P.window_advance;
+            const f32x4 xrN4 = load_xref(tab + oz, wstart, N - 1);
+            const float xrN[3] = {xrN4[0], xrN4[1], xrN4[2]};
+            M.terminal(xrN, pterm);
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++) a[i][0] = a[i][1] = a[i][2] = a[i][3] = 0.f; // y = g = 0 (:106-107)
+    }
+    } // MPC steps
 
     if (P.max_iter <= 0) // tiny_solve only sets status and iter (admm.cpp:114-117,151)
     {
@@ -721,6 +831,12 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
             P.iter[inst] = itn;
             if (!solved) atomicAdd(P.n_unsolved, 1);
         }
+        if (MPC && valid) // the host's plant step of the last solve continues from here
+        {
+#pragma unroll
+            for (int v = 0; v < 3; v++) P.x0buf[inst * NX + 4 * v + g] = x0[v];
+            if (g == 0 && P.xref_mode == 1) P.xref_start[inst] = wstart;
+        }
     }
     } // tile queue
 }
@@ -749,7 +865,8 @@ hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t
     const size_t lds = (size_t)(TILE16_WAVES * N * WAVE + 2 * N * 4 + rows * 4) * sizeof(float4);
 #define TINY_TILE16_LAUNCH(NN, EX)                                                                                         \
     {                                                                                                                      \
-        auto kern = P.cold_start ? admm_tile16_kernel<NN, EX, true> : admm_tile16_kernel<NN, EX, false>;                  \
+        auto kern = P.mpc_steps > 1 ? (P.cold_start ? admm_tile16_kernel<NN, EX, true, true> : admm_tile16_kernel<NN, EX, false, true>) \
+                                    : (P.cold_start ? admm_tile16_kernel<NN, EX, true> : admm_tile16_kernel<NN, EX, false>); \
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         if (e != hipSuccess) return e;                                                                                     \
         hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WAVE * TILE16_WAVES), lds, stream, P);                                \

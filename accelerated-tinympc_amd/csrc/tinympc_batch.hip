@@ -843,6 +843,9 @@ int row_family(const TinyBatch *tb)
     // better with four instances per wave, and a closed-loop run keeps the kernel whose MPC loop stays on chip
     // (a caller that hands over its own dispatch order lists groups of four instances: the automatic choice then stays with the
     // kernel that order is for)
+    // (round 4: tile16's MPC loop stays on chip too — tiny_batch_set_row_kernel(tb, 5) — but the warm-started solves of a closed loop are short and
+    //  uneven, and sixteen instances in lock step lose more there than the matrix cores gain: measured 1.02 ms per MPC step of 65 536 tracking
+    //  instances against 0.97 ms on the 16-lane kernel, so the automatic choice of a closed-loop run stays with the latter)
     if (tile16_applies(tb) && !tb->closed_loop_run && !tb->order_dev && tb->batch >= kTile16AutoBatch) return 5;
     if (tb->row_dims_ok) return 0;
     if (tb->rowloop_ok) return 1;
@@ -1648,14 +1651,17 @@ int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, 
     TRY(prepare_solve(tb, &v));
     const size_t u0n = (size_t)tb->batch * tb->nu;
     const int fam = v != VAR_STREAM ? row_family(tb) : -1;
-    if ((fam == 0 || fam == 4) && !tb->h16 && steps > 1 && bounds_all_shared(tb))
+    if ((fam == 0 || fam == 4 || fam == 5) && !tb->h16 && steps > 1 && bounds_all_shared(tb))
     {
         RowParams P;
         fill_row_params(tb, P, v == VAR_ROW_EXACT);
         P.mpc_steps = steps; P.window_advance = window_advance; P.u0_traj = d_u0_traj;
+        if (fam == 5) P.order = nullptr; // a caller's order lists groups of four instances, not tiles (index order inside a closed-loop run)
+        tb->last_dispatch = P.order ? 2 : 0;
         HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, 2 * sizeof(int), tb->stream)); // [0] unsolved count, [1] tile queue of admm_tile16.hip
-        hipError_t e = fam == 0 ? launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, false, P, tb->stream)
-                                : launch_admm_quadlane(tb->N, v == VAR_ROW_EXACT, false, P, tb->stream);
+        hipError_t e = fam == 0   ? launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, false, P, tb->stream)
+                       : fam == 5 ? launch_admm_tile16(tb->N, v == VAR_ROW_EXACT, P, tb->stream)
+                                  : launch_admm_quadlane(tb->N, v == VAR_ROW_EXACT, false, P, tb->stream);
         if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
         if (d_u0_traj) TRY(launch_unpack(tb, work_ptr(tb, TINY_ARR_U), d_u0_traj + (size_t)(steps - 1) * u0n, tb->layout, 1, tb->batch, 0, 1));
         TRY(enqueue_plant_step(tb, window_advance));

@@ -26,12 +26,13 @@ while time.time() < t_end:
     settings = dict(abs_pri_tol=float(rng.choice([1e-3, 1e-2])), abs_dua_tol=float(rng.choice([1e-3, 1e-1])), max_iter=int(rng.choice([1, 3, 20, 60])),
                     check_termination=int(rng.choice([1, 1, 2, 5])), en_state_bound=int(rng.integers(2)), en_input_bound=int(rng.integers(2)))
     variant = int(rng.choice([2, 3, 1])) if kind != "odd" or True else 2
-    fam = int(rng.choice([0, 0, 1, 2, 3, 4]))
+    fam = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 5]))   # 5 = tile16 (round 4: its MPC loop stays on chip too)
     K, adv = int(rng.integers(1, 9)), int(rng.choice([0, 1, 2]))
     table = (rng.standard_normal((N + 60, nx)) * 0.1).astype(np.float32)
     start = rng.integers(0, 40, size=B).astype(np.int32)
     x0 = rng.uniform(-0.2, 0.2, size=(B, nx)).astype(np.float32)
     windowed = rng.random() < 0.6
+    shared_ref = fam == 5 and rng.random() < 0.5   # one shared reference: the other mode the 16-instances-per-wave kernel serves
     sols = []
     for _ in range(2):
         s = T.TinyBatchSolver(prob, B, settings=settings)
@@ -44,12 +45,14 @@ while time.time() < t_end:
         s.set_bounds(*pr.bounds_arrays(prob))
         if windowed:
             s.set_xref_window(table, start)
+        elif shared_ref:
+            s.set_xref(table[:N])
         else:
             s.set_xref(pr.expand_windows(table, start, N))
         s.set_x0(x0)
         sols.append(s)
     a, b = sols
-    onchip += a.kernel_name().startswith(("rowlane", "quadlane")) and K > 1
+    onchip += a.kernel_name().startswith(("rowlane", "quadlane", "tile16")) and K > 1
     for rnd in range(2):
         a.mpc_run_async(K, adv)
         for _ in range(K):

@@ -136,10 +136,15 @@ SCRATCH_PINS = {
     # the persistent tile16 kernels keep their tile-invariant values (gains, tables' bases, the -0 accumulator) live across the whole
     # tile body and spill a few dozen registers around prologue and epilogue; the ITERATION LOOP must stay (almost) free of scratch
     # traffic, which test_tile16_iteration_loop_is_free_of_scratch_traffic checks separately
-    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb1ELb1EEE"): 116,
-    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb1ELb0EEE"): 196,
-    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb1EEE"): 136,
-    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb0EEE"): 48,
+    # <N, EXACT, COLD, MPC>; MPC = the closed loop on chip (round 4)
+    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb1ELb1ELb0EEE"): 116,
+    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb1ELb0ELb0EEE"): 196,
+    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb1ELb0EEE"): 136,
+    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb0ELb0EEE"): 48,
+    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb1ELb1ELb1EEE"): 92,
+    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb1ELb0ELb1EEE"): 196,
+    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb1ELb1EEE"): 0,
+    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb0ELb1EEE"): 44,
     # the nx = 32 tile kernel keeps no state in registers (duals in LDS, slack streamed): nothing may spill
     # (round 4: <EXACT, TWO> — TWO is the instantiation for horizons whose duals leave room for a second workgroup per CU: it must also stay
     #  within 256 registers, which test_tile48_short_horizon_instantiation_fits_two_waves_per_simd checks)

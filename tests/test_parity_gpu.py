@@ -1746,8 +1746,8 @@ def test_predicted_longest_first_dispatch(tinympc, oracle_mod, exact, family):
             assert_bitwise({k: res[1][0][k][idx] for k in STATE_ORDER + SCALARS}, st, "dispatch 1 vs oracle")
 
 
-CLOSED_LOOP_CASES = [("hover", "row_exact"), ("hover", "loop_exact"), ("hover", "rowstream_exact"),
-                     ("track", "row_exact"), ("track", "loop_exact"), ("track", "rowstream_exact"),
+CLOSED_LOOP_CASES = [("hover", "row_exact"), ("hover", "loop_exact"), ("hover", "rowstream_exact"), ("hover", "tile_exact"),
+                     ("track", "row_exact"), ("track", "loop_exact"), ("track", "rowstream_exact"), ("track", "tile_exact"),
                      ("cartpole", "row_exact"), ("cartpole", "lane_exact"), ("cartpole", "loop_exact"),
                      ("dims837", "row_exact"), ("dims837", "loop_exact")]
 
