@@ -141,10 +141,12 @@ SCRATCH_PINS = {
     ("admm_tile16.hip", "admm_tile16_kernelILi30ELb1ELb0ELb0EEE"): 196,
     ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb1ELb0EEE"): 136,
     ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb0ELb0EEE"): 48,
-    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb1ELb1ELb1EEE"): 92,
-    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb1ELb0ELb1EEE"): 196,
-    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb1ELb1EEE"): 0,
-    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb0ELb1EEE"): 44,
+    # (the MPC instantiations spill around the block between two solves — plant step, deferred sweep, slack restore — which runs once per
+    #  MPC step; their iteration loop is held to the same bound as the others by test_tile16_iteration_loop_is_free_of_scratch_traffic)
+    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb1ELb1ELb1EEE"): 352,
+    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb1ELb0ELb1EEE"): 316,
+    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb1ELb1EEE"): 152,
+    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb0ELb1EEE"): 224,
     # the nx = 32 tile kernel keeps no state in registers (duals in LDS, slack streamed): nothing may spill
     # (round 4: <EXACT, TWO> — TWO is the instantiation for horizons whose duals leave room for a second workgroup per CU: it must also stay
     #  within 256 registers, which test_tile48_short_horizon_instantiation_fits_two_waves_per_simd checks)
