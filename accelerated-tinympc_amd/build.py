@@ -17,7 +17,7 @@ CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libtinympc_hip.so"
 WRAPPER_LIB = PKG / "lib" / "libtinympc_wrapper.so"  # same-name twin of the reference's generated wrapper library
 WRAPPER64_LIB = PKG / "lib" / "libtinympc_wrapper64.so"  # the native names (tiny_solve, forward_pass, ...) for tinytype = double
-SOURCES = ["tinympc_batch.hip", "tinympc_batch64.hip", "admm_stream.hip", "admm_rowlane.hip", "admm_rowloop.hip", "admm_quadlane.hip", "admm_tile16.hip", "admm_wave.hip", "admm_waveres.hip", "admm_tile48.hip", "admm_steps.hip", "dispatch_order.hip", "riccati.cpp"]
+SOURCES = ["tinympc_batch.hip", "tinympc_batch64.hip", "admm_stream.hip", "admm_generic.hip", "admm_rowlane.hip", "admm_rowloop.hip", "admm_quadlane.hip", "admm_tile16.hip", "admm_wave.hip", "admm_waveres.hip", "admm_tile48.hip", "admm_steps.hip", "dispatch_order.hip", "riccati.cpp"]
 WRAPPER_SRCS = [CSRC / "wrapper_compat.cpp", CSRC / "admm_compat.cpp"]
 HEADERS = [CSRC / "tinympc_internal.h", CSRC / "rowlane_math.h", CSRC / "tile_math.h", CSRC / "wave_math.h", CSRC / "dpp_ops_gen.h", PKG.parent / "include" / "tinympc_batch.h", PKG.parent / "include" / "tinympc_batch64.h"]
 # -ffp-contract=off : exact arithmetic must not fuse a*b+c; the fast paths call fma explicitly
@@ -101,7 +101,7 @@ def device_asm(source: str) -> Path:
 # kernel family (the name tiny_batch_kernel_name() reports, up to the '<') -> the translation unit that holds its device code
 KERNEL_SOURCES = {"rowlane": "admm_rowlane.hip", "rowloop": "admm_rowloop.hip", "rowstream": "admm_steps.hip", "quadlane": "admm_quadlane.hip",
                   "tile16": "admm_tile16.hip", "tile48": "admm_tile48.hip", "waveres": "admm_waveres.hip", "wavestream": "admm_wave.hip",
-                  "stream": "admm_stream.hip", "rows64": "tinympc_batch64.hip", "thread64": "tinympc_batch64.hip"}
+                  "stream": "admm_stream.hip", "generic": "admm_generic.hip", "rows64": "tinympc_batch64.hip", "thread64": "tinympc_batch64.hip"}
 
 
 def _elf_sections(b: bytes, base: int = 0) -> dict:

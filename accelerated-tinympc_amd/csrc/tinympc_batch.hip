@@ -51,7 +51,8 @@ int fail(int code, const char *fmt, ...)
     if (!(p)) return fail(TINY_BATCH_EINVAL, "%s: NULL pointer argument '%s'", __func__, #p)
 
 enum { LAYOUT_TILE = 0, LAYOUT_ROW = 1 };
-enum { VAR_AUTO = 0, VAR_STREAM = 1, VAR_ROW_EXACT = 2, VAR_ROW_FAST = 3 };
+enum { VAR_AUTO = 0, VAR_STREAM = 1, VAR_ROW_EXACT = 2, VAR_ROW_FAST = 3, VAR_GENERIC = 4 }; // 4: admm_generic.hip, exact arithmetic for any eligible class
+inline bool tile_variant(int v) { return v == VAR_STREAM || v == VAR_GENERIC; } // the variants that work on the TILE layout
 
 // ---------------------------------------------------------------------------------------------
 // Element addressing of the two device layouts.  `fam` 0 = state-type (nx rows, N steps),
@@ -248,6 +249,8 @@ struct TinyBatch
     bool tile16_ok = false; // admm_tile16.hip has an instantiation for (nx, nu, N)
     bool waveres_ok = false; // admm_waveres.hip serves (nx, nu, N): wave class with N <= 50
     bool tile48_ok = false;  // admm_tile48.hip does (nx = 32, nu = 16, N = 50: sixteen instances per workgroup on the matrix cores)
+    bool generic_ok = false; // admm_generic.hip: exact arithmetic with run-time dimensions (nx, nu each <= 4 or a multiple of 4)
+    float *gen_mats = nullptr; // its gains: Kinf | Pinf | Quu_inv | AmBKt | Adyn | Bdyn | Q, column-major
     int *conv_dev = nullptr; // [batch] result of termination_condition
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr; // created by tiny_batch_group_solve / mpc_run for handles left on the null stream
@@ -626,6 +629,12 @@ int pack_gains(TinyBatch *tb)
             TRY(upload_vec(tb, fast ? &tb->mats_fast : &tb->mats_exact, m));
         }
     }
+    if (tb->generic_ok)
+    {
+        std::vector<float> gm;
+        for (const std::vector<float> *m : {&tb->Kinf, &tb->Pinf, &tb->Quu_inv, &tb->AmBKt, &tb->Adyn, &tb->Bdyn, &tb->Q}) gm.insert(gm.end(), m->begin(), m->end());
+        TRY(upload_vec(tb, &tb->gen_mats, gm));
+    }
     if (!tb->dA) HIP_TRY(hipMalloc((void **)&tb->dA, (size_t)nx * nx * sizeof(float)));
     if (!tb->dB) HIP_TRY(hipMalloc((void **)&tb->dB, (size_t)nx * nu * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(tb->dA, A, (size_t)nx * nx * sizeof(float), hipMemcpyHostToDevice, tb->stream));
@@ -768,12 +777,16 @@ int resolve_variant(TinyBatch *tb, int *out)
     {
         // the automatic choice is exact arithmetic or nothing: a class without a compiled exact kernel runs in fma arithmetic on the padded
         // MFMA kernel only when the caller has asked for it by name (round 4: it used to be selected silently)
-        if (!row_ok)
-            return fail(TINY_BATCH_EUNSUPPORTED, "nx=%d nu=%d has no exact-arithmetic kernel (TINY_FOR_EACH_ROWDIMS / _WAVEDIMS); "
-                                                 "tiny_batch_select_kernel(tb, 1) opts into fma arithmetic on the MFMA streaming kernel", tb->nx, tb->nu);
-        v = VAR_ROW_EXACT;
+        if (!row_ok && !tb->generic_ok)
+            return fail(TINY_BATCH_EUNSUPPORTED, "nx=%d nu=%d has no exact-arithmetic kernel (the reference's own summation order depends on column alignment "
+                                                 "unless nx and nu are each <= 4 or a multiple of 4); tiny_batch_select_kernel(tb, 1) opts into fma arithmetic "
+                                                 "on the MFMA streaming kernel", tb->nx, tb->nu);
+        v = row_ok ? VAR_ROW_EXACT : VAR_GENERIC; // a class outside the compiled lists: exact arithmetic with run-time dimensions (admm_generic.hip)
     }
-    if ((tb->en_uref || tb->en_d2p) && (!tb->rowmath_ok || v == VAR_STREAM))
+    if (v == VAR_GENERIC && (!tb->generic_ok || tb->h16 || tb->en_uref || tb->en_d2p))
+        return fail(TINY_BATCH_EUNSUPPORTED, "the run-time-dimension exact kernel (variant 4) needs nx, nu each <= 4 or a multiple of 4 (nx <= 64, nu <= 32), "
+                                             "fp32 storage and no optional terms (nx=%d nu=%d)", tb->nx, tb->nu);
+    if ((tb->en_uref || tb->en_d2p) && (!tb->rowmath_ok || tile_variant(v)))
         return fail(TINY_BATCH_EUNSUPPORTED, "the optional Uref / coeff_d2p terms (tiny_batch_set_optional_terms) are implemented by the row "
                                              "kernels for nx + nu <= 16 only (nx=%d nu=%d, variant %d)", tb->nx, tb->nu, v);
     if ((v == VAR_ROW_EXACT || v == VAR_ROW_FAST) && !row_ok)
@@ -858,9 +871,10 @@ void update_kname(TinyBatch *tb)
     char nm[96];
     const std::string keep = g_err;
     if (resolve_variant(tb, &v)) { tb->kname = "unsupported"; g_err = keep; return; }
-    const bool d32 = tb->h16 && (tb->dual32_forced ? tb->dual32 : (tb->dual32_pref && v != VAR_STREAM && family_keeps_fp32_duals(row_family(tb))));
+    const bool d32 = tb->h16 && (tb->dual32_forced ? tb->dual32 : (tb->dual32_pref && !tile_variant(v) && family_keeps_fp32_duals(row_family(tb))));
     const char *ar = v == VAR_ROW_EXACT ? "exact" : "fast", *sto = tb->h16 ? (d32 ? ",h16d" : ",h16") : "";
     if (v == VAR_STREAM) snprintf(nm, sizeof nm, "stream<%d,%d>", tb->NXC, tb->NUC);
+    else if (v == VAR_GENERIC) snprintf(nm, sizeof nm, "generic<%d,%d,exact>", tb->nx, tb->nu);
     else if (row_family(tb) == 0) snprintf(nm, sizeof nm, "rowlane<%d,%d,%d,%s%s>", tb->nx, tb->nu, tb->N, ar, sto);
     else if (row_family(tb) == 1) snprintf(nm, sizeof nm, "rowloop<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
     else if (row_family(tb) == 3) snprintf(nm, sizeof nm, "wavestream<%d,%d,%s>", tb->nx, tb->nu, ar);
@@ -961,7 +975,7 @@ int prepare_solve(TinyBatch *tb, int *variant)
         TRY(dev_alloc_zero((float **)&tb->order_buf, (size_t)tb->bpad4 / 4));
     }
     {
-        const int layout = (v == VAR_STREAM) ? LAYOUT_TILE : LAYOUT_ROW;
+        const int layout = tile_variant(v) ? LAYOUT_TILE : LAYOUT_ROW;
         TRY(ensure_layout(tb, layout));
         TRY(settle_dual_width(tb, layout == LAYOUT_ROW && family_keeps_fp32_duals(row_family(tb))));
         TRY(prepare_inputs(tb, layout));
@@ -982,7 +996,7 @@ constexpr int kDispatchMinGroups = 4096; // two rounds of waves on 256 CUs x 4 S
 
 int enqueue_solve(TinyBatch *tb, int v, bool record_events)
 {
-    const int layout = (v == VAR_STREAM) ? LAYOUT_TILE : LAYOUT_ROW;
+    const int layout = tile_variant(v) ? LAYOUT_TILE : LAYOUT_ROW;
     HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, 2 * sizeof(int), tb->stream)); // [0] unsolved count, [1] tile queue of admm_tile16.hip
     // longest-first dispatch (dispatch_order.hip): predictor sweep + bucket sort ahead of the register-resident 16-lane kernels;
     // pays off only when the launch is several rounds of waves deep
@@ -1020,7 +1034,7 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
         P.xref_table = tb->tab_tile; P.xref_start = tb->xref_start; P.table_rows = tb->table_rows;
         P.res = tb->res; P.status = tb->status; P.iter = tb->iter; P.n_unsolved = tb->n_unsolved;
         P.opnd = tb->opnd; P.qvec = tb->qvec;
-        e = launch_admm_stream(tb->NXC, tb->NUC, P, tb->stream);
+        e = v == VAR_GENERIC ? launch_admm_generic(P, tb->gen_mats, tb->NXC, tb->NUC, tb->stream) : launch_admm_stream(tb->NXC, tb->NUC, P, tb->stream);
     }
     else
     {
@@ -1130,6 +1144,7 @@ int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int dev
     tb->tile16_ok = tb->rowmath_ok && tile16_supported(nx, nu, N);
     tb->waveres_ok = wave_ok && waveres_supported(nx, nu, N);
     tb->tile48_ok = wave_ok && tile48_supported(nx, nu, N);
+    tb->generic_ok = tile_ok && generic_exact_supported(nx, nu);
     tb->rw = wave_ok ? 64 : 16;
     tb->xfam_floats = (size_t)tb->ntiles * N * WAVE * nxc;
     tb->ufam_floats = (size_t)tb->ntiles * (N - 1) * WAVE * nuc;
@@ -1166,7 +1181,7 @@ void tiny_batch_destroy(TinyBatch *tb)
     (void)hipFree(tb->t_xref); (void)hipFree(tb->r_xref); (void)hipFree(tb->r_bounds);
     (void)hipFree(tb->tab_tile); (void)hipFree(tb->tab_row); (void)hipFree(tb->tab_row_h); (void)hipFree(tb->xref_start);
     (void)hipFree(tb->res); (void)hipFree(tb->status); (void)hipFree(tb->iter); (void)hipFree(tb->n_unsolved);
-    (void)hipFree(tb->opnd); (void)hipFree(tb->qvec); (void)hipFree(tb->mats_exact); (void)hipFree(tb->mats_fast);
+    (void)hipFree(tb->opnd); (void)hipFree(tb->qvec); (void)hipFree(tb->gen_mats); (void)hipFree(tb->mats_exact); (void)hipFree(tb->mats_fast);
     (void)hipFree(tb->dA); (void)hipFree(tb->dB); (void)hipFree(tb->x0buf); (void)hipFree(tb->staging); (void)hipFree(tb->conv_dev);
     if (tb->graph_exec) (void)hipGraphExecDestroy(tb->graph_exec);
     if (tb->own_stream) (void)hipStreamDestroy(tb->own_stream);
@@ -1650,7 +1665,7 @@ int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, 
     tb->closed_loop_run = steps > 1;
     TRY(prepare_solve(tb, &v));
     const size_t u0n = (size_t)tb->batch * tb->nu;
-    const int fam = v != VAR_STREAM ? row_family(tb) : -1;
+    const int fam = !tile_variant(v) ? row_family(tb) : -1;
     if ((fam == 0 || fam == 4 || fam == 5) && !tb->h16 && steps > 1 && bounds_all_shared(tb))
     {
         RowParams P;
@@ -1779,7 +1794,7 @@ int tiny_batch_arithmetic(TinyBatch *tb)
     CHECK_TB(tb);
     int v = 0;
     TRY(resolve_variant(tb, &v));
-    return v == VAR_ROW_EXACT ? TINY_BATCH_ARITH_EXACT : TINY_BATCH_ARITH_FMA;
+    return (v == VAR_ROW_EXACT || v == VAR_GENERIC) ? TINY_BATCH_ARITH_EXACT : TINY_BATCH_ARITH_FMA;
 }
 
 int tiny_batch_set_row_kernel(TinyBatch *tb, int family)
@@ -1847,15 +1862,15 @@ int tiny_batch_set_storage_ex(TinyBatch *tb, int bits, int dual_bits)
 int tiny_batch_select_kernel(TinyBatch *tb, int variant)
 {
     CHECK_TB(tb);
-    if (variant < VAR_AUTO || variant > VAR_ROW_FAST)
-        return fail(TINY_BATCH_EINVAL, "variant must be 0 (auto), 1 (streaming), 2 (rowlane exact) or 3 (rowlane fast)");
+    if (variant < VAR_AUTO || variant > VAR_GENERIC)
+        return fail(TINY_BATCH_EINVAL, "variant must be 0 (auto), 1 (streaming, fma), 2 (row / wave kernels, exact), 3 (row / wave kernels, fma) or 4 (run-time dimensions, exact)");
     const int old = tb->variant;
     tb->variant = variant;
     int v = 0;
     if (int rc = resolve_variant(tb, &v)) { tb->variant = old; return rc; }
     invalidate_graph(tb);
     TRY(set_device(tb));
-    TRY(ensure_layout(tb, v == VAR_STREAM ? LAYOUT_TILE : LAYOUT_ROW));
+    TRY(ensure_layout(tb, tile_variant(v) ? LAYOUT_TILE : LAYOUT_ROW));
     return 0;
 }
 

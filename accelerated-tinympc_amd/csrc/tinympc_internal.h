@@ -154,6 +154,10 @@ bool tile48_supported(int nx, int nu, int N);
 hipError_t launch_admm_tile48(int N, bool exact, const RowParams &P, hipStream_t stream);
 
 hipError_t launch_admm_stream(int nxc, int nuc, const SolveParams &P, hipStream_t stream);
+// exact arithmetic with RUN-TIME dimensions, one thread per instance, TILE layout (admm_generic.hip): any nx <= 64, nu <= 32 with nx, nu each <= 4 or a
+// multiple of 4; gains = Kinf | Pinf | Quu_inv | AmBKt | Adyn | Bdyn | Q (column-major)
+bool generic_exact_supported(int nx, int nu);
+hipError_t launch_admm_generic(const SolveParams &P, const float *gains, int nxc, int nuc, hipStream_t stream);
 
 // longest-first dispatch order of the instance groups for the register-resident row kernel (dispatch_order.hip);
 // P.mats must be the fma gains

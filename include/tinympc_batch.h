@@ -64,11 +64,14 @@ extern "C"
      * (types.hpp:26-107, quadrotor_hovering.cpp:25-28).
      * Dimensions (glob_opts.hpp:5-7 fixes them at compile time; here they are arguments): any nx <= 64, nu <= 32, N >= 2.
      * Classes with a compiled exact kernel — (nx, nu) = (12,4), (4,1), (8,3), (8,4), (12,2), (4,2), (4,4), (32,16), (16,8),
-     * (16,4), (20,8), (24,4) — compute bitwise what the reference computes.  Any other class has the MFMA streaming kernel in FMA
-     * arithmetic only (results within the reference's own fp64-vs-fp32 spread, not bitwise): the automatic kernel choice never
-     * lands there by itself (round 4) — a solve on such a handle returns TINY_BATCH_EUNSUPPORTED until the caller opts in with
-     * tiny_batch_select_kernel(tb, 1); tiny_batch_arithmetic() says what a solve would compute in.  Beyond those limits create
-     * itself returns TINY_BATCH_EUNSUPPORTED. */
+     * (16,4), (20,8), (24,4) — have fast exact kernels and compute bitwise what the reference computes.  Any other class with
+     * nx <= 36 and nx, nu each <= 4 or a multiple of 4 is served, also bitwise, by the run-time-dimension exact kernel (round 4,
+     * "generic<nx,nu,exact>": no rebuild, slow).  The remaining classes (e.g. nu = 7, nx = 40: the reference's own summation order
+     * depends on column alignment there, or lies beyond what is pinned) have the MFMA streaming kernel in FMA arithmetic only
+     * (results within the reference's own fp64-vs-fp32 spread, not bitwise): the automatic kernel choice never lands there by
+     * itself — a solve on such a handle returns TINY_BATCH_EUNSUPPORTED until the caller opts in with
+     * tiny_batch_select_kernel(tb, 1); tiny_batch_arithmetic() says what a solve would compute in.  Beyond nx <= 64, nu <= 32
+     * create itself returns TINY_BATCH_EUNSUPPORTED. */
     int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int device);
     void tiny_batch_destroy(TinyBatch *tb);
     /* Launch on this hipStream_t (passed as void*; NULL = the null stream).  Default: NULL. */
@@ -196,11 +199,14 @@ extern "C"
      *   < 0: no kernel would run (TINY_BATCH_EUNSUPPORTED; tiny_batch_last_error() names the opt-in). */
     enum { TINY_BATCH_ARITH_EXACT = 0, TINY_BATCH_ARITH_FMA = 1 };
     int tiny_batch_arithmetic(TinyBatch *tb);
-    /* Force a kernel variant: 0 = auto (exact arithmetic when the class has an exact kernel — nx + nu <= 16: row
-     * kernels, 16 < nx + nu <= 64: wave-per-instance kernel — and the bounds are batch-shared, else streaming),
-     * 1 = streaming MFMA kernel (state in HBM, fma arithmetic), 2 = exact arithmetic (bitwise equal to the reference's
-     * SSE2 build), 3 = fma arithmetic on the row kernels (nx + nu <= 16)
-     * or on the state-on-chip wave kernel (16 < nx + nu <= 64, N <= 50).  Bounds may be batch-shared or per instance in
+    /* Force a kernel variant: 0 = auto = EXACT arithmetic: the compiled kernels of the class (nx + nu <= 16: row kernels,
+     * 16 < nx + nu <= 64: wave / tile kernels) or, for a class outside the compiled lists, the run-time-dimension kernel 4;
+     * 1 = streaming MFMA kernel (state in HBM, fma arithmetic; the only kernel of a class whose dimensions admit no exact order),
+     * 2 = exact arithmetic on the compiled kernels (bitwise equal to the reference's SSE2 build), 3 = fma arithmetic on the row
+     * kernels (nx + nu <= 16) or on the state-on-chip wave / tile kernels (16 < nx + nu <= 64, N <= 50),
+     * 4 = exact arithmetic with run-time dimensions (admm_generic.hip: one thread per instance, state in HBM; any nx <= 36, nu <= 32
+     * with nx, nu each <= 4 or a multiple of 4 — the classes the reference's summation orders are defined and pinned for; bitwise
+     * equal to the reference compiled for that class; the any-class fallback, slow).  Bounds may be batch-shared or per instance in
      * every variant (per-instance bounds stay on the register-resident 16-lane kernels for N <= 64; the quad kernel and longer
      * horizons hand over to the kernels that stream their state). */
     int tiny_batch_select_kernel(TinyBatch *tb, int variant);

@@ -191,6 +191,11 @@ class Oracle(_Solver):
                 raise ValueError(f"{name}={rows}: the reference's summation order for results with rows >= {ps} and rows % {ps} != 0 "
                                  "depends on the 16-byte alignment of each destination column (Eigen LinearVectorized "
                                  "assignment) and is not restated; see the header of tinympc_oracle_impl.h")
+            if 3 * rows - 1 > 110 and not allow_unpinned_dims:
+                # round 4: measured against the compiled reference for nx = 40 and nx = 64 — beyond Eigen's complete-unrolling limit
+                # (3n - 1 <= EIGEN_UNROLLING_LIMIT = 110, n <= 37) the coefficient-evaluated products are NOT the plain sequential loop
+                # this restatement falls back to; nothing above 37 is pinned, so nothing above 37 is claimed
+                raise ValueError(f"{name}={rows}: reduction orders beyond Eigen's unrolling limit (n > 37) are not restated")
         self.lib = _lib()
         self.PS = _problem_struct(self.T)
         self.BS = _batch_struct(self.T)

@@ -70,7 +70,10 @@ CFGS = [(np.float32, 12, 4, 30), (np.float64, 12, 4, 30), (np.float64, 12, 4, 10
         (np.float32, 8, 4, 9), (np.float32, 12, 2, 11), (np.float32, 4, 2, 8), (np.float32, 4, 4, 6), (np.float64, 8, 4, 9),
         (np.float32, 16, 8, 10), (np.float32, 16, 4, 10), (np.float32, 20, 8, 10), (np.float32, 24, 4, 10),
         (np.float64, 12, 2, 11), (np.float64, 4, 2, 8), (np.float64, 4, 4, 6), (np.float64, 16, 4, 10),
-        (np.float32, 2, 2, 3), (np.float64, 2, 2, 3)]  # examples/codegen_random.cpp:19-21
+        (np.float32, 2, 2, 3), (np.float64, 2, 2, 3),  # examples/codegen_random.cpp:19-21
+        # round 4: classes OUTSIDE the compiled kernel lists whose orders the rules still define (nx, nu each <= 4 or a multiple of 4): what the
+        # run-time-dimension exact kernel (admm_generic.hip) is held to
+        (np.float32, 20, 12, 12), (np.float32, 3, 2, 6), (np.float32, 8, 8, 6), (np.float32, 4, 3, 9), (np.float32, 36, 4, 5), (np.float32, 28, 16, 6)]
 
 
 @pytest.mark.parametrize("dt,nx,nu,N", CFGS)
@@ -246,6 +249,24 @@ def test_oracle_refuses_dims_whose_reference_result_depends_on_alignment(oracle_
     with pytest.raises(ValueError):
         O.Oracle(prob, np.float32)
     O.Oracle(tinympc.problems.random_system(8, 3, 7, seed=1), np.float32)  # nu < packet size: fine
+    # round 4: beyond Eigen's complete-unrolling limit (3n - 1 <= 110) the restatement's sequential fallback is NOT what the compiled reference
+    # does (measured for nx = 40 and nx = 64 against oracle/_ref): refused too, and the product's exact kernels stop at nx = 36 for the same reason
+    for nx, nu, N in ((40, 12, 6), (64, 32, 4)):
+        with pytest.raises(ValueError):
+            O.Oracle(tinympc.problems.random_system(nx, nu, N, seed=nx * 31 + nu), np.float32)
+        if O.have_ref(np.float32, nx, nu, N):
+            prob = tinympc.problems.random_system(nx, nu, N, seed=nx * 31 + nu)
+            rng = np.random.default_rng(nx)
+            st0 = O.new_state(3, nx, nu, N)
+            for k in O.STATE_ORDER:
+                st0[k][:] = (rng.standard_normal(st0[k].shape) * 0.3).astype(np.float32)
+            a, b = O.copy_state(st0), O.copy_state(st0)
+            bn = tinympc.problems.bounds_arrays(prob)
+            xr = (rng.standard_normal((3, N, nx)) * 0.2).astype(np.float32)
+            s = dict(max_iter=1, abs_pri_tol=0, abs_dua_tol=0)
+            O.Oracle(prob, np.float32, s, allow_unpinned_dims=True).solve(a, *bn, xr)
+            O.Reference(prob, np.float32, s).solve(b, *bn, xr)
+            assert not np.array_equal(a["p"], b["p"]), "the sequential fallback now equals the reference: the refusal can go"
 
 
 def test_oracle_and_host_riccati_under_address_and_ub_sanitizers(tmp_path):

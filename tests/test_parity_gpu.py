@@ -1209,11 +1209,14 @@ def test_classes_without_an_instantiation_run_on_the_padded_mfma_kernel(tinympc,
         sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
         sol.set_bounds(*bnds); sol.set_xref(xref); sol.set_x0(x0)
         # round 4: the arithmetic mode is a contract — the automatic choice is exact arithmetic or nothing, fma arithmetic is an opt-in
-        assert sol.kernel_name() == "unsupported"
-        with pytest.raises(tinympc.TinyBatchError, match="opts into fma"):
-            sol.arithmetic()
-        with pytest.raises(tinympc.TinyBatchError, match="opts into fma"):
-            sol.solve()
+        if all(d <= 4 or d % 4 == 0 for d in (nx, nu)) and nx <= 36:   # the reference's orders are defined: the run-time-dimension exact kernel
+            assert sol.kernel_name() == f"generic<{nx},{nu},exact>" and sol.arithmetic() == "exact", sol.kernel_name()
+        else:
+            assert sol.kernel_name() == "unsupported"
+            with pytest.raises(tinympc.TinyBatchError, match="opts into fma"):
+                sol.arithmetic()
+            with pytest.raises(tinympc.TinyBatchError, match="opts into fma"):
+                sol.solve()
         sol.select_kernel(1)
         assert sol.kernel_name().startswith("stream<") and sol.arithmetic() == "fma", sol.kernel_name()
         sol.solve()
@@ -2057,6 +2060,78 @@ def test_default_16_bit_storage_keeps_the_duals_in_fp32_where_a_register_residen
         sol.set_storage(16, 16)
         assert sol.kernel_name().endswith(",h16>"), sol.kernel_name()
         sol.close()
+
+
+GENERIC_DIMS = [(20, 12, 12), (3, 2, 6), (8, 8, 6), (4, 3, 9), (36, 4, 5), (28, 16, 6)]
+
+
+@pytest.mark.parametrize("dims", GENERIC_DIMS)
+def test_generic_exact_kernel_bitwise_vs_compiled_reference(tinympc, oracle_mod, dims):
+    """Round 4 (review: "bitwise arithmetic outside the compiled class lists"): a class with no compiled exact kernel but with dimensions the
+    reference's orders are defined for (nx, nu each <= 4 or a multiple of 4, nx <= 36) is solved in EXACT arithmetic by the
+    run-time-dimension kernel (admm_generic.hip) — the automatic choice, no rebuild — bit for bit what the reference COMPILED FOR THAT CLASS
+    computes (oracle/_ref, built by oracle/Makefile; the oracle where the GPU box has no such build): warm states with signed zeros,
+    four settings, shared and per-instance bounds, shared / per-instance / windowed references, cold starts, chains of solves."""
+    O, pr = oracle_mod, tinympc.problems
+    nx, nu, N = dims
+    prob = pr.random_system(nx, nu, N, seed=nx * 100 + nu)
+    Ref = O.Reference if O.have_ref(np.float32, nx, nu, N) else O.Oracle
+    rng = np.random.default_rng(nx + nu + N)
+    B = 37
+    st0 = O.new_state(B, nx, nu, N)
+    for k in STATE_ORDER:
+        st0[k][:] = (rng.standard_normal(st0[k].shape) * 0.3).astype(np.float32)
+    for k in ("x", "d", "v", "z", "g", "y"):
+        st0[k][rng.random(st0[k].shape) < 0.1] = 0.0
+        st0[k][rng.random(st0[k].shape) < 0.1] = -0.0
+    st0["x"][0, 0] = -0.0; st0["g"][0] = 0.0; st0["y"][0] = 0.0; st0["d"][0] = 0.0
+    shared = pr.bounds_arrays(prob)
+    per_inst = tuple((a[None] * rng.uniform(0.3, 1.0, size=(B,) + a.shape)).astype(np.float32) for a in shared)
+    table = (rng.standard_normal((N + 20, nx)) * 0.2).astype(np.float32)
+    start = rng.integers(0, 20, size=B).astype(np.int32)
+    refs = {"shared": (rng.standard_normal((N, nx)) * 0.2).astype(np.float32), "per_instance": (rng.standard_normal((B, N, nx)) * 0.2).astype(np.float32),
+            "window": None}
+    cases = [(dict(max_iter=1, abs_pri_tol=0, abs_dua_tol=0), shared, "per_instance"), (dict(max_iter=12, abs_pri_tol=0, abs_dua_tol=0), per_inst, "shared"),
+             (dict(max_iter=60, check_termination=3), shared, "window"), (dict(max_iter=5, en_state_bound=0, en_input_bound=0), per_inst, "per_instance")]
+    for extra, bnds, refmode in cases:
+        settings = dict(O.DEFAULT_SETTINGS, **extra)
+        sol = tinympc.TinyBatchSolver(prob, B, settings=settings)
+        assert sol.kernel_name() == f"generic<{nx},{nu},exact>" and sol.arithmetic() == "exact", sol.kernel_name()
+        sol.set_bounds(*bnds)
+        if refmode == "window":
+            sol.set_xref_window(table, start); xref = pr.expand_windows(table, start, N)
+        else:
+            xref = refs[refmode]; sol.set_xref(xref)
+        st = O.copy_state(st0)
+        sol.set_state(st)
+        ref = Ref(prob, np.float32, settings)
+        for k in range(3):   # a warm solve, then two with the duals reset
+            if k:
+                st["y"][:] = 0; st["g"][:] = 0; sol.reset_dual_variables()
+            rc_ref = ref.solve(st, *bnds, xref)
+            rc = sol.solve()
+            assert (rc != 0) == (rc_ref != 0)
+            assert_bitwise(sol.get_state(), st, f"generic {dims} {extra} k={k}")
+        # a cold start (reset_workspace folded into the launch)
+        x0 = rng.uniform(-0.5, 0.5, size=(B, nx)).astype(np.float32)
+        sol.reset_workspace(); sol.set_x0(x0)
+        st = O.new_state(B, nx, nu, N); st["x"][:, 0] = x0
+        ref.solve(st, *bnds, xref); sol.solve()
+        assert_bitwise(sol.get_state(), st, f"generic {dims} {extra} cold")
+        sol.close()
+    # the same kernel on a COMPILED class, on request (variant 4), equals that class's own exact kernel
+    if dims == GENERIC_DIMS[0]:
+        q = pr.quadrotor(20, 10)
+        x0, tb_, s_ = pr.tracking_batch(64, 10, seed=3)
+        outs = []
+        for variant in (0, 4):
+            sol = tinympc.TinyBatchSolver(q, 64)
+            sol.select_kernel(variant)
+            sol.set_bounds(*pr.bounds_arrays(q)); sol.set_xref_window(tb_, s_); sol.set_x0(x0)
+            sol.solve(); sol.reset_dual_variables(); sol.solve()
+            outs.append((sol.kernel_name(), sol.get_state())); sol.close()
+        assert outs[1][0] == "generic<12,4,exact>" and outs[0][0].startswith("rowlane<12,4,10,exact")
+        assert_bitwise(outs[1][1], outs[0][1], "generic vs rowlane on the quadrotor class")
 
 
 def test_arithmetic_mode_is_reported_by_the_library(tinympc):
