@@ -36,9 +36,17 @@ namespace tinympc
 #define TINY_BPI_AHEAD 4
 #endif
 constexpr int BPI_AHEAD = TINY_BPI_AHEAD;
-template <int NX, int NU, int N, bool EXACT, bool H16, bool MPC = false, bool BPI = false, bool D32 = false>
+// OPT = true (round 4): the two terms the reference ships commented out (admm.cpp:20 "+ coeff_d2p * d.col(i)", :79 Uref; off by default,
+// tiny_batch_set_optional_terms) on this register-resident kernel — until now a handle that enabled one was routed to the kernel that streams
+// its state.  The input rows of the cost register c hold d, so -(Uref .* R) is not kept: an input lane reads its Uref element of step i
+// OPT_AHEAD steps ahead from the [B or 1][N][16] array (4 bytes per lane-step, L2 resident) where the linear cost is formed; coeff_d2p * d_i is
+// one more DPP product group behind the Riccati step (rowlane_math.h d2p_term: added to the STORED p_i, in sequential order, as Eigen does).
+// fp32 storage, batch-shared bounds, one solve per launch.
+constexpr int OPT_AHEAD = 4;
+template <int NX, int NU, int N, bool EXACT, bool H16, bool MPC = false, bool BPI = false, bool D32 = false, bool OPT = false>
 __global__ __launch_bounds__(WAVE, (N > 32 && EXACT && !H16) ? 1 : 2) void admm_rowlane_kernel(const RowParams P)
 {
+    static_assert(!OPT || (!H16 && !MPC && !BPI && !D32), "the optional terms are instantiated for fp32 storage, shared bounds, one solve per launch");
     constexpr bool HD = H16 && !D32; // storage precision of the duals (gy)
     const int lane = threadIdx.x;
     const int r16 = lane & 15;
@@ -71,6 +79,24 @@ __global__ __launch_bounds__(WAVE, (N > 32 && EXACT && !H16) ? 1 : 2) void admm_
     // ---- gain rows of this lane -----------------------------------------------------------------
     RowGains<NX, NU> G;
     G.load(P.mats, r16);
+    // optional terms (OPT): R(r) on the input rows, coeff_d2p(r, m) on the state rows (pack_gains), this lane's Uref column
+    [[maybe_unused]] float rrow = 0.f, CD[NU];
+    [[maybe_unused]] const bool uref_on = OPT && P.uref != nullptr, d2p_on = OPT && P.en_d2p != 0;
+    [[maybe_unused]] const int uref_off = inst_a * (int)P.uref_inst_stride + r16;
+    if constexpr (OPT)
+    {
+        rrow = P.mats[(3 * NX + 2 * NU + 1) * 16 + r16];
+#pragma unroll
+        for (int m = 0; m < NU; m++) CD[m] = P.mats[(3 * NX + 2 * NU + 2 + m) * 16 + r16];
+    }
+    // cost term of step i as lin_cost() wants it: -(Xref_i .* Q) on the state rows; on the input rows -0 (so that r = -rho (znew - y) keeps the
+    // sign of a zero difference) or, with the Uref term on, -(Uref_i .* R)   (admm.cpp:79-82)
+    auto cost_of_step = [&](float ci, [[maybe_unused]] float ur) -> float {
+        float cq = cost_term(ci, is_x);
+        if constexpr (OPT)
+            if (uref_on) cq = is_u ? -(ur * rrow) : cq;
+        return cq;
+    };
 
     // ---- per-instance state ------------------------------------------------------------------------------
     //   a[i]  : g_i (x rows) | y_i (u rows)           duals                                (VGPR)
@@ -205,15 +231,31 @@ __global__ __launch_bounds__(WAVE, (N > 32 && EXACT && !H16) ? 1 : 2) void admm_
                 ran_bwd = true;
                 const bool upd_d = is_u && !keep_d;
                 float sn_pref = sn[(N - 2) * WAVE];
+                [[maybe_unused]] float ur_ring[OPT_AHEAD];
+                if constexpr (OPT)
+                    if (uref_on)
+                    {
+#pragma unroll
+                        for (int k = 0; k < OPT_AHEAD; k++) ur_ring[k] = P.uref[uref_off + (N - 2 - k > 0 ? N - 2 - k : 0) * 16];
+                    }
 #pragma unroll
                 for (int i = N - 2; i >= 0; i--)
                 {
                     const float sni = sn_pref;
                     sn_pref = sn[(i > 0 ? i - 1 : 0) * WAVE]; // LDS read one step ahead
                     const float t1 = sni - a[i];
-                    const float cq = cost_term(c[i], is_x); // x rows: -(Xref.*Q) ; u rows: -0
+                    float ur = 0.f;
+                    if constexpr (OPT)
+                        if (uref_on)
+                        {
+                            ur = ur_ring[(N - 2 - i) % OPT_AHEAD];
+                            if (i - OPT_AHEAD >= 0) ur_ring[(N - 2 - i) % OPT_AHEAD] = P.uref[uref_off + (i - OPT_AHEAD) * 16]; // its slot was consumed just now
+                        }
+                    const float cq = cost_of_step(c[i], ur); // x rows: -(Xref.*Q) ; u rows: -0 (or -(Uref.*R))
                     float pn, dd;
                     riccati_step<NX, NU, EXACT, H16>(G, is_x, p, lin_cost<EXACT, H16>(cq, rho, t1), pn, dd); // admm.cpp:19-20,80-82
+                    if constexpr (OPT)
+                        if (d2p_on) pn = d2p_term<NX, NU, EXACT, H16>(CD, pn, dd); // "+ coeff_d2p * d.col(i)" (admm.cpp:20)
                     c[i] = upd_d ? dd : c[i];
                     b[i * WAVE] = sni;                     // admm.cpp:141-142
                     pd[i] = is_u ? dd : pn;                // [p_i ; d_i] of this sweep (live-out only: stays in registers)
@@ -279,7 +321,10 @@ __global__ __launch_bounds__(WAVE, (N > 32 && EXACT && !H16) ? 1 : 2) void admm_
             s = xn;
             const float sni = sn[i * WAVE];
             const float t1 = sni - a[i];
-            const float cq = cost_term(c[i], is_x);
+            float ur = 0.f;
+            if constexpr (OPT)
+                if (uref_on) ur = P.uref[uref_off + i * 16];
+            const float cq = cost_of_step(c[i], ur);
             const float lin = lin_cost<EXACT, H16>(cq, rho, t1);
             stw<H16>(P.qr, o, (i < N - 1 || is_x) ? lin : 0.f);
             // p.col(N-1) is rewritten by every forward sweep (admm.cpp:83-84); the other columns and d were stored by the
@@ -342,6 +387,19 @@ hipError_t launch_admm_rowlane(int nx, int nu, int N, bool exact, bool h16, cons
         return hipGetLastError();                                                                                        \
     }
         TINY_FOR_EACH_ROWLANE(TINY_ROWLANE_BPI_DISPATCH)
+        return hipErrorInvalidValue;
+    }
+    if (P.uref != nullptr || P.en_d2p) // the optional terms (round 4): fp32 storage, batch-shared bounds
+    {
+        if (h16 || P.dual32) return hipErrorInvalidValue;
+#define TINY_ROWLANE_OPT_DISPATCH(NX, NU, NN)                                                                            \
+    if (nx == NX && nu == NU && N == NN)                                                                                 \
+    {                                                                                                                    \
+        if (exact) hipLaunchKernelGGL((admm_rowlane_kernel<NX, NU, NN, true, false, false, false, false, true>), dim3(nblocks), dim3(WAVE), 0, stream, P);  \
+        else hipLaunchKernelGGL((admm_rowlane_kernel<NX, NU, NN, false, false, false, false, false, true>), dim3(nblocks), dim3(WAVE), 0, stream, P);      \
+        return hipGetLastError();                                                                                        \
+    }
+        TINY_FOR_EACH_ROWLANE(TINY_ROWLANE_OPT_DISPATCH)
         return hipErrorInvalidValue;
     }
     if (P.dual32) // fp16 storage with fp32 duals

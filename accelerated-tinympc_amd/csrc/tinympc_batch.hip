@@ -837,6 +837,11 @@ int row_family(const TinyBatch *tb)
     }
     // per-instance bounds: the unrolled register-resident kernel (fp32 storage) and the rolled-loop ones (N <= 64, either storage)
     // read them from the [B][N][16] table, the streaming row kernel serves every other case; the quad kernel stages one shared table
+    // the optional terms (Uref, coeff_d2p): on the unrolled register-resident kernel since round 4 (fp32 storage, batch-shared bounds, one solve per
+    // launch); every other combination — fp16 storage, per-instance bounds, a closed-loop run, another forced family — on the streaming row kernel
+    if ((tb->en_uref || tb->en_d2p) && tb->row_dims_ok && !tb->h16 && bounds_all_shared(tb) && !tb->closed_loop_run &&
+        (tb->row_family_forced < 0 || tb->row_family_forced == 0))
+        return 0;
     if (!bounds_all_shared(tb))
     {
         if (tb->en_uref || tb->en_d2p) return 2;

@@ -1573,7 +1573,12 @@ def test_optional_terms_vs_oracle(tinympc, oracle_mod, case, exact):
         with pytest.raises(tinympc.TinyBatchError):  # enabled but R / Uref / coeff_d2p not given yet
             sol.solve()
         sol.set_input_cost(prob["R"]); sol.set_coeff_d2p(prob["coeff_d2p"]); sol.set_uref(uref)
-        assert sol.kernel_name().startswith("rowstream"), sol.kernel_name()
+        # round 4: with fp32 storage (and batch-shared bounds) the terms live in the register-resident kernel where the class has one —
+        # no reroute to the kernel that streams its state; fp16 storage still takes that one
+        if storage == 32 and default_kernel.startswith(("rowlane", "quadlane")):
+            assert sol.kernel_name().startswith("rowlane"), (default_kernel, sol.kernel_name())
+        else:
+            assert sol.kernel_name().startswith("rowstream"), sol.kernel_name()
         dt = "h16" if storage == 16 else np.float32
         orc = O.Oracle(prob, dt, settings)
         orc.set_uref(R16(uref))
