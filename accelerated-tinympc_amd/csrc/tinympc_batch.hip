@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -49,6 +51,61 @@ int fail(int code, const char *fmt, ...)
     if (!(tb)) return fail(TINY_BATCH_EINVAL, "%s: NULL TinyBatch handle", __func__)
 #define CHECK_PTR(p) \
     if (!(p)) return fail(TINY_BATCH_EINVAL, "%s: NULL pointer argument '%s'", __func__, #p)
+
+// ---------------------------------------------------------------------------------------------
+// Debug guard zones ("a debug bounds-checked kernel variant" — GPU AddressSanitizer does not exist on this pool).
+// With tiny_batch_debug_guards(1) every device allocation of this library is made kGuard floats larger at both ends; the guards are filled
+// with a quiet-NaN pattern.  An out-of-bounds WRITE of any kernel then lands in a guard and tiny_batch_debug_check() counts the
+// damaged words; an out-of-bounds READ returns NaN, which no parity test survives.  It is a mode of the same library — the kernels
+// are the shipped ones, unchanged — used by tests/test_parity_gpu.py::test_debug_guard_zones_stay_intact over every kernel family.
+// ---------------------------------------------------------------------------------------------
+constexpr size_t kGuard = 256;               // floats on each side (1 KB: keeps the 256-byte alignment of hipMalloc)
+constexpr unsigned kGuardWord = 0x7fc0dea1u; // a quiet NaN
+std::mutex g_guard_mu;
+std::map<void *, size_t> g_guarded;          // user pointer -> user bytes
+bool g_guards_on = false;
+
+__global__ void guard_fill_kernel(unsigned *p, size_t nwords)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nwords; e += (size_t)gridDim.x * blockDim.x) p[e] = kGuardWord;
+}
+__global__ void guard_count_kernel(const unsigned *p, size_t nwords, unsigned long long *bad)
+{
+    unsigned long long n = 0;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nwords; e += (size_t)gridDim.x * blockDim.x) n += p[e] != kGuardWord;
+    if (n) atomicAdd(bad, n);
+}
+
+hipError_t guarded_malloc(void **out, size_t bytes)
+{
+    if (!g_guards_on) return hipMalloc(out, bytes);
+    const size_t user = (bytes + 3) / 4 * 4;
+    char *raw = nullptr;
+    hipError_t e = hipMalloc((void **)&raw, user + 2 * kGuard * sizeof(float));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(guard_fill_kernel, dim3(1), dim3(256), 0, nullptr, (unsigned *)raw, kGuard);
+    hipLaunchKernelGGL(guard_fill_kernel, dim3(1), dim3(256), 0, nullptr, (unsigned *)(raw + kGuard * sizeof(float) + user), kGuard);
+    e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) { (void)hipFree(raw); return e; }
+    *out = raw + kGuard * sizeof(float);
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guarded[*out] = user;
+    return hipSuccess;
+}
+hipError_t guarded_free(void *p)
+{
+    if (!p) return hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        auto it = g_guarded.find(p);
+        if (it != g_guarded.end())
+        {
+            g_guarded.erase(it);
+            return hipFree((char *)p - kGuard * sizeof(float));
+        }
+    }
+    return hipFree(p);
+}
 
 enum { LAYOUT_TILE = 0, LAYOUT_ROW = 1 };
 enum { VAR_AUTO = 0, VAR_STREAM = 1, VAR_ROW_EXACT = 2, VAR_ROW_FAST = 3, VAR_GENERIC = 4 }; // 4: admm_generic.hip, exact arithmetic for any eligible class
@@ -340,7 +397,7 @@ int set_device(TinyBatch *tb)
 
 int dev_alloc_zero(float **p, size_t nfloats)
 {
-    HIP_TRY(hipMalloc((void **)p, nfloats * sizeof(float)));
+    HIP_TRY(guarded_malloc((void **)p, nfloats * sizeof(float)));
     HIP_TRY(hipMemset(*p, 0, nfloats * sizeof(float)));
     // hipMemset of device memory is enqueued on the null stream and may return early; a handle on a non-blocking
     // stream would not be ordered behind it
@@ -371,9 +428,9 @@ int alloc_layout(TinyBatch *tb, int layout)
 void free_layout(TinyBatch *tb, int layout)
 {
     if (layout == LAYOUT_ROW)
-        for (int p = 0; p < 6; p++) { (void)hipFree(tb->pair[p]); tb->pair[p] = nullptr; }
+        for (int p = 0; p < 6; p++) { (void)guarded_free(tb->pair[p]); tb->pair[p] = nullptr; }
     else
-        for (int id = 0; id < TINY_ARR_COUNT; id++) { (void)hipFree(tb->arr[id]); tb->arr[id] = nullptr; }
+        for (int id = 0; id < TINY_ARR_COUNT; id++) { (void)guarded_free(tb->arr[id]); tb->arr[id] = nullptr; }
 }
 
 int launch_pack(TinyBatch *tb, const float *src, float *dst, int layout, int fam, int nb, bool shared, int step0, int nsteps)
@@ -487,8 +544,8 @@ int download_work(TinyBatch *tb, int id, float *host, int step0, int nsteps)
 int store_input(TinyBatch *tb, InputArr &in, const float *host, bool shared, int steps, int dim)
 {
     const size_t n = (size_t)(shared ? 1 : tb->batch) * steps * dim;
-    if (in.dev && in.shared != shared) { (void)hipFree(in.dev); in.dev = nullptr; }
-    if (!in.dev) HIP_TRY(hipMalloc((void **)&in.dev, n * sizeof(float)));
+    if (in.dev && in.shared != shared) { (void)guarded_free(in.dev); in.dev = nullptr; }
+    if (!in.dev) HIP_TRY(guarded_malloc((void **)&in.dev, n * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(in.dev, host, n * sizeof(float), hipMemcpyHostToDevice, tb->stream));
     HIP_TRY(hipStreamSynchronize(tb->stream));
     in.shared = shared;
@@ -536,7 +593,7 @@ void pack_one(const TinyBatch *tb, std::vector<float> &out, int t_out, int ch_in
 
 int upload_vec(TinyBatch *tb, float **dst, const std::vector<float> &v)
 {
-    if (!*dst) HIP_TRY(hipMalloc((void **)dst, v.size() * sizeof(float)));
+    if (!*dst) HIP_TRY(guarded_malloc((void **)dst, v.size() * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice, tb->stream));
     HIP_TRY(hipStreamSynchronize(tb->stream)); // `v` may be a temporary
     return 0;
@@ -635,8 +692,8 @@ int pack_gains(TinyBatch *tb)
         for (const std::vector<float> *m : {&tb->Kinf, &tb->Pinf, &tb->Quu_inv, &tb->AmBKt, &tb->Adyn, &tb->Bdyn, &tb->Q}) gm.insert(gm.end(), m->begin(), m->end());
         TRY(upload_vec(tb, &tb->gen_mats, gm));
     }
-    if (!tb->dA) HIP_TRY(hipMalloc((void **)&tb->dA, (size_t)nx * nx * sizeof(float)));
-    if (!tb->dB) HIP_TRY(hipMalloc((void **)&tb->dB, (size_t)nx * nu * sizeof(float)));
+    if (!tb->dA) HIP_TRY(guarded_malloc((void **)&tb->dA, (size_t)nx * nx * sizeof(float)));
+    if (!tb->dB) HIP_TRY(guarded_malloc((void **)&tb->dB, (size_t)nx * nu * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(tb->dA, A, (size_t)nx * nx * sizeof(float), hipMemcpyHostToDevice, tb->stream));
     HIP_TRY(hipMemcpyAsync(tb->dB, B, (size_t)nx * nu * sizeof(float), hipMemcpyHostToDevice, tb->stream));
     HIP_TRY(hipStreamSynchronize(tb->stream));
@@ -673,7 +730,7 @@ int prepare_inputs(TinyBatch *tb, int layout)
         if (!bounds_all_shared(tb)) // per-instance bounds: [bpad4][N][rw]{lo,hi}, built on the device from the canonical inputs
         {
             const size_t nf = (size_t)tb->bpad4 * N * RW * 2;
-            if (tb->r_bounds) { (void)hipFree(tb->r_bounds); tb->r_bounds = nullptr; }
+            if (tb->r_bounds) { (void)guarded_free(tb->r_bounds); tb->r_bounds = nullptr; }
             TRY(dev_alloc_zero(&tb->r_bounds, tb->h16 ? (nf + 1) / 2 : nf));
             const InputArr *in = tb->in_bnd;
             hipLaunchKernelGGL(bounds_table_kernel, dim3(grid_for((long long)tb->batch * N * RW)), dim3(256), 0, tb->stream,
@@ -709,21 +766,21 @@ int prepare_inputs(TinyBatch *tb, int layout)
             for (size_t e = 0; e < tab.size(); e++) th[e] = (_Float16)tab[e];
             std::vector<float> packed((tab.size() + 1) / 2);
             std::memcpy(packed.data(), th.data(), packed.size() * sizeof(float));
-            if (tb->r_bounds) { (void)hipFree(tb->r_bounds); tb->r_bounds = nullptr; }
+            if (tb->r_bounds) { (void)guarded_free(tb->r_bounds); tb->r_bounds = nullptr; }
             TRY(upload_vec(tb, &tb->r_bounds, packed));
         }
         else
         {
-            if (tb->r_bounds) { (void)hipFree(tb->r_bounds); tb->r_bounds = nullptr; }
+            if (tb->r_bounds) { (void)guarded_free(tb->r_bounds); tb->r_bounds = nullptr; }
             TRY(upload_vec(tb, &tb->r_bounds, tab));
         }
         }
         const size_t nf = (size_t)(tb->in_xref.set && !tb->in_xref.shared ? tb->bpad4 : 1) * N * RW;
-        if (tb->r_xref) { (void)hipFree(tb->r_xref); tb->r_xref = nullptr; }
+        if (tb->r_xref) { (void)guarded_free(tb->r_xref); tb->r_xref = nullptr; }
         TRY(dev_alloc_zero(&tb->r_xref, tb->h16 ? (nf + 1) / 2 : nf));
         if (tb->in_xref.set)
             TRY(launch_pack(tb, tb->in_xref.dev, tb->r_xref, LAYOUT_ROW, 0, tb->in_xref.shared ? 1 : tb->batch, tb->in_xref.shared, 0, N));
-        if (tb->r_uref) { (void)hipFree(tb->r_uref); tb->r_uref = nullptr; }
+        if (tb->r_uref) { (void)guarded_free(tb->r_uref); tb->r_uref = nullptr; }
         if (tb->in_uref.set) // Uref on the u rows of an [inst][N][rw] array of its own (row N-1 and the x rows stay zero)
         {
             const size_t nu_f = (size_t)(tb->in_uref.shared ? 1 : tb->bpad4) * N * RW;
@@ -755,7 +812,7 @@ int settle_dual_width(TinyBatch *tb, bool kernel_keeps_fp32_duals)
         hipLaunchKernelGGL(dual_width_kernel, dim3(grid_for((long long)tb->pair_floats)), dim3(256), 0, tb->stream, tb->pair[5], nw, (long long)tb->pair_floats, want32 ? 1 : 0);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(tb->stream));
-        (void)hipFree(tb->pair[5]);
+        (void)guarded_free(tb->pair[5]);
         tb->pair[5] = nw;
     }
     tb->dual32 = want32;
@@ -1179,15 +1236,15 @@ void tiny_batch_destroy(TinyBatch *tb)
     (void)hipSetDevice(tb->device);
     free_layout(tb, LAYOUT_TILE);
     free_layout(tb, LAYOUT_ROW);
-    (void)hipFree(tb->in_xref.dev);
-    (void)hipFree(tb->in_uref.dev); (void)hipFree(tb->r_uref);
-    (void)hipFree(tb->key_buf); (void)hipFree(tb->order_buf); (void)hipFree(tb->u0_stage);
-    for (int k = 0; k < 4; k++) { (void)hipFree(tb->in_bnd[k].dev); (void)hipFree(tb->t_bnd[k]); }
-    (void)hipFree(tb->t_xref); (void)hipFree(tb->r_xref); (void)hipFree(tb->r_bounds);
-    (void)hipFree(tb->tab_tile); (void)hipFree(tb->tab_row); (void)hipFree(tb->tab_row_h); (void)hipFree(tb->xref_start);
-    (void)hipFree(tb->res); (void)hipFree(tb->status); (void)hipFree(tb->iter); (void)hipFree(tb->n_unsolved);
-    (void)hipFree(tb->opnd); (void)hipFree(tb->qvec); (void)hipFree(tb->gen_mats); (void)hipFree(tb->mats_exact); (void)hipFree(tb->mats_fast);
-    (void)hipFree(tb->dA); (void)hipFree(tb->dB); (void)hipFree(tb->x0buf); (void)hipFree(tb->staging); (void)hipFree(tb->conv_dev);
+    (void)guarded_free(tb->in_xref.dev);
+    (void)guarded_free(tb->in_uref.dev); (void)guarded_free(tb->r_uref);
+    (void)guarded_free(tb->key_buf); (void)guarded_free(tb->order_buf); (void)guarded_free(tb->u0_stage);
+    for (int k = 0; k < 4; k++) { (void)guarded_free(tb->in_bnd[k].dev); (void)guarded_free(tb->t_bnd[k]); }
+    (void)guarded_free(tb->t_xref); (void)guarded_free(tb->r_xref); (void)guarded_free(tb->r_bounds);
+    (void)guarded_free(tb->tab_tile); (void)guarded_free(tb->tab_row); (void)guarded_free(tb->tab_row_h); (void)guarded_free(tb->xref_start);
+    (void)guarded_free(tb->res); (void)guarded_free(tb->status); (void)guarded_free(tb->iter); (void)guarded_free(tb->n_unsolved);
+    (void)guarded_free(tb->opnd); (void)guarded_free(tb->qvec); (void)guarded_free(tb->gen_mats); (void)guarded_free(tb->mats_exact); (void)guarded_free(tb->mats_fast);
+    (void)guarded_free(tb->dA); (void)guarded_free(tb->dB); (void)guarded_free(tb->x0buf); (void)guarded_free(tb->staging); (void)guarded_free(tb->conv_dev);
     if (tb->graph_exec) (void)hipGraphExecDestroy(tb->graph_exec);
     if (tb->own_stream) (void)hipStreamDestroy(tb->own_stream);
     if (tb->ev0) (void)hipEventDestroy(tb->ev0);
@@ -1362,7 +1419,7 @@ int tiny_batch_set_xref_window(TinyBatch *tb, const float *table, int rows, cons
         }
     if (tb->table_rows != rows)
     {
-        (void)hipFree(tb->tab_tile); (void)hipFree(tb->tab_row); (void)hipFree(tb->tab_row_h);
+        (void)guarded_free(tb->tab_tile); (void)guarded_free(tb->tab_row); (void)guarded_free(tb->tab_row_h);
         tb->tab_tile = tb->tab_row = tb->tab_row_h = nullptr;
     }
     TRY(upload_vec(tb, &tb->tab_tile, tt));
@@ -1501,7 +1558,7 @@ int tiny_batch_group_get_u0(TinyBatch **tbs, int n, float *u0_host)
     for (int i = 0; i < n; i++) { CHECK_TB(tbs[i]); total += (size_t)tbs[i]->batch * tbs[i]->nu; }
     TRY(set_device(tbs[0]));
     float *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, total * sizeof(float)));
+    HIP_TRY(guarded_malloc((void **)&d, total * sizeof(float)));
     int rc = tiny_batch_group_gather_u0(tbs, n, tbs[0]->device, d);
     if (rc == 0)
     {
@@ -1510,7 +1567,7 @@ int tiny_batch_group_get_u0(TinyBatch **tbs, int n, float *u0_host)
         if (e != hipSuccess) rc = fail(TINY_BATCH_EHIP, "tiny_batch_group_get_u0: %s", hipGetErrorString(e));
     }
     (void)hipSetDevice(tbs[0]->device);
-    (void)hipFree(d);
+    (void)guarded_free(d);
     return rc;
 }
 
@@ -1620,8 +1677,8 @@ int tiny_batch_set_xref_device(TinyBatch *tb, const float *d_xref, int shared)
     InputArr &in = tb->in_xref;
     const bool sh = shared != 0;
     const size_t n = (size_t)(sh ? 1 : tb->batch) * tb->N * tb->nx;
-    if (in.dev && in.shared != sh) { (void)hipFree(in.dev); in.dev = nullptr; }
-    if (!in.dev) HIP_TRY(hipMalloc((void **)&in.dev, n * sizeof(float)));
+    if (in.dev && in.shared != sh) { (void)guarded_free(in.dev); in.dev = nullptr; }
+    if (!in.dev) HIP_TRY(guarded_malloc((void **)&in.dev, n * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(in.dev, d_xref, n * sizeof(float), hipMemcpyDeviceToDevice, tb->stream));
     in.shared = sh;
     in.set = true;
@@ -1747,7 +1804,7 @@ int tiny_batch_mpc_run_traj(TinyBatch *tb, int steps, int window_advance, float 
     TRY(set_device(tb));
     const size_t n = (size_t)steps * tb->batch * tb->nu;
     float *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, n * sizeof(float)));
+    HIP_TRY(guarded_malloc((void **)&d, n * sizeof(float)));
     int rc = tiny_batch_mpc_run_traj_async(tb, steps, window_advance, d);
     if (rc == 0)
     {
@@ -1755,7 +1812,7 @@ int tiny_batch_mpc_run_traj(TinyBatch *tb, int steps, int window_advance, float 
         if (e == hipSuccess) e = hipMemcpy(u0_traj_host, d, n * sizeof(float), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(TINY_BATCH_EHIP, "tiny_batch_mpc_run_traj: %s", hipGetErrorString(e));
     }
-    (void)hipFree(d);
+    (void)guarded_free(d);
     return rc;
 }
 
@@ -1792,6 +1849,50 @@ const char *tiny_batch_kernel_name(TinyBatch *tb)
     if (!tb) return "";
     update_kname(tb);
     return tb->kname.c_str();
+}
+
+int tiny_batch_debug_guards(int on)
+{
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guards_on = on != 0; // applies to allocations made from now on (handles created earlier keep what they have)
+    return 0;
+}
+
+long long tiny_batch_debug_check(void)
+{
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    if (g_guarded.empty()) return 0;
+    unsigned long long *bad = nullptr, host = 0;
+    if (hipMalloc((void **)&bad, sizeof *bad) != hipSuccess || hipMemset(bad, 0, sizeof *bad) != hipSuccess) return fail(TINY_BATCH_EHIP, "tiny_batch_debug_check: allocation failed");
+    if (hipDeviceSynchronize() != hipSuccess) { (void)hipFree(bad); return fail(TINY_BATCH_EHIP, "tiny_batch_debug_check: a kernel faulted: %s", hipGetErrorString(hipGetLastError())); }
+    for (const auto &kv : g_guarded)
+    {
+        char *u = (char *)kv.first;
+        hipLaunchKernelGGL(guard_count_kernel, dim3(1), dim3(256), 0, nullptr, (const unsigned *)(u - kGuard * sizeof(float)), kGuard, bad);
+        hipLaunchKernelGGL(guard_count_kernel, dim3(1), dim3(256), 0, nullptr, (const unsigned *)(u + kv.second), kGuard, bad);
+    }
+    hipError_t e = hipMemcpy(&host, bad, sizeof host, hipMemcpyDeviceToHost);
+    (void)hipFree(bad);
+    if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "tiny_batch_debug_check: %s", hipGetErrorString(e));
+    return (long long)host;
+}
+
+int tiny_batch_debug_poke(TinyBatch *tb, int which)
+{
+    CHECK_TB(tb);
+    TRY(set_device(tb));
+    // test hook of the guard zones: deliberately writes ONE word just outside a work array of this handle (which = 0: in front, 1: behind)
+    float *arr = tb->layout == LAYOUT_ROW ? tb->pair[0] : tb->arr[0];
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        auto it = g_guarded.find(arr);
+        if (it == g_guarded.end()) return fail(TINY_BATCH_ENOTREADY, "tiny_batch_debug_poke: the handle was not created under tiny_batch_debug_guards(1)");
+        bytes = it->second;
+    }
+    const float v = 1.0f;
+    HIP_TRY(hipMemcpy(which ? (char *)arr + bytes : (char *)arr - sizeof(float), &v, sizeof v, hipMemcpyHostToDevice));
+    return 0;
 }
 
 int tiny_batch_arithmetic(TinyBatch *tb)

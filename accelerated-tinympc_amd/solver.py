@@ -109,11 +109,27 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
     lib.tiny_batch64_destroy.argtypes, lib.tiny_batch64_destroy.restype = [P], None
     lib.tiny_batch64_last_error.argtypes, lib.tiny_batch64_last_error.restype = [], C.c_char_p
     lib.tiny_batch64_kernel_name.argtypes, lib.tiny_batch64_kernel_name.restype = [P], C.c_char_p
+    lib.tiny_batch_debug_guards.argtypes, lib.tiny_batch_debug_guards.restype = [C.c_int], C.c_int
+    lib.tiny_batch_debug_check.argtypes, lib.tiny_batch_debug_check.restype = [], C.c_longlong
+    lib.tiny_batch_debug_poke.argtypes, lib.tiny_batch_debug_poke.restype = [P, C.c_int], C.c_int
     lib.tiny_batch_destroy.argtypes, lib.tiny_batch_destroy.restype = [P], None
     lib.tiny_batch_last_error.argtypes, lib.tiny_batch_last_error.restype = [], C.c_char_p
     lib.tiny_batch_kernel_name.argtypes, lib.tiny_batch_kernel_name.restype = [P], C.c_char_p
     _lib = lib
     return lib
+
+
+def debug_guards(on: bool):
+    """tiny_batch_debug_guards: guard zones around every device allocation made from now on (the debug mode of SURVEY.md section 5)."""
+    load_library().tiny_batch_debug_guards(1 if on else 0)
+
+
+def debug_check() -> int:
+    """tiny_batch_debug_check: guard words overwritten so far by any kernel (0 = no out-of-bounds write); raises on a HIP error."""
+    n = load_library().tiny_batch_debug_check()
+    if n < 0:
+        raise TinyBatchError(f"tiny_batch_debug_check: {load_library().tiny_batch_last_error().decode()} ({n})")
+    return int(n)
 
 
 def exported_symbols():

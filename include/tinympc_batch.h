@@ -191,6 +191,15 @@ extern "C"
     /* Name of the kernel variant the next solve will launch ("rowlane<12,4,30,exact>", "rowstream<12,4,fast>",
      * "stream<3,1>", with ",h16" appended under fp16 storage). */
     const char *tiny_batch_kernel_name(TinyBatch *tb);
+    /* Debug guard zones (the stand-in for a GPU address sanitizer, which this platform does not offer).
+     * tiny_batch_debug_guards(1): every device allocation this library makes FROM NOW ON carries 1 KB of quiet-NaN guard words at
+     * both ends (handles created before keep what they have).  tiny_batch_debug_check() waits for the device and returns the number of
+     * guard words any kernel has overwritten (0 = no out-of-bounds write anywhere; < 0: a HIP error, e.g. a fault); an out-of-bounds
+     * READ returns NaN and surfaces in the results.  The kernels are the shipped ones.  tiny_batch_debug_poke writes one word just
+     * outside a work array of a guarded handle (which = 0 in front, 1 behind): the self-test of the checker. */
+    int tiny_batch_debug_guards(int on);
+    long long tiny_batch_debug_check(void);
+    int tiny_batch_debug_poke(TinyBatch *tb, int which);
     /* The ARITHMETIC the next solve computes in — the contract behind the kernel name:
      *   TINY_BATCH_ARITH_EXACT (0): every product and sum a separately rounded operation in the reference's order: results bitwise
      *                               equal to the compiled reference (tinytype = float, SSE2 build);

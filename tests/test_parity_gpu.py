@@ -2067,6 +2067,74 @@ def test_default_16_bit_storage_keeps_the_duals_in_fp32_where_a_register_residen
         sol.close()
 
 
+def test_debug_guard_zones_stay_intact(tinympc):
+    """SURVEY.md section 5 asks for a debug bounds-checked variant (there is no GPU address sanitizer on this platform).  Under
+    tiny_batch_debug_guards(1) every device allocation of the library carries NaN guard zones; this sweep drives EVERY kernel family
+    (unrolled / rolled / streaming row kernels, quad, tile16 incl. its on-chip closed loop, wave kernels, tile48, MFMA streaming, the
+    run-time-dimension kernel, the six step functions, fp16 storage, per-instance bounds, optional terms, pack / unpack / plant / predictor
+    helpers) over ragged batch sizes and then asks the library how many guard words were overwritten: none, and no result is NaN (an
+    out-of-bounds read would return the guard pattern).  The checker itself is tested with a deliberate out-of-bounds write."""
+    pr = tinympc.problems
+    tinympc.debug_guards(True)
+    try:
+        assert tinympc.debug_check() == 0
+        rng = np.random.default_rng(11)
+        runs = []   # (problem, batch, variant, family, extra)
+        q30, q17, q77, cp, r32, odd, gen = pr.quadrotor(20, 30), pr.quadrotor(20, 17), pr.quadrotor(20, 77), pr.cartpole(10), \
+            pr.random_system(32, 16, 50, seed=1234), pr.random_system(8, 3, 7, seed=99), pr.random_system(20, 12, 12, seed=2012)
+        for B in (1, 17, 203):
+            runs += [(q30, B, 2, 1, {}), (q30, B, 3, 1, {}), (q30, B, 2, 2, {}), (q30, B, 2, 3, {}), (q30, B, 2, 5, {}), (q30, B, 3, 5, {}), (q30, B, 1, 0, {}),
+                     (q30, B, 2, 1, dict(per_instance_bounds=True)), (q30, B, 2, 0, dict(storage=16)), (q30, B, 2, 1, dict(optional=True)),
+                     (q17, B, 2, 0, {}), (q77, B, 2, 0, {}), (cp, B, 2, 0, {}), (cp, B, 2, 1, {}), (odd, B, 2, 0, {}),
+                     (r32, B, 2, 6, {}), (r32, B, 2, 7, {}), (r32, B, 2, 8, {}), (r32, B, 3, 8, {}), (r32, B, 1, 0, {}), (gen, B, 0, 0, {}), (q30, B, 4, 0, {})]
+        names = set()
+        for prob, B, variant, family, extra in runs:
+            nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+            sol = tinympc.TinyBatchSolver(prob, B, settings=dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=7, check_termination=2, en_state_bound=1, en_input_bound=1))
+            if extra.get("storage"):
+                sol.set_storage(extra["storage"])
+            sol.select_kernel(variant)
+            if family:
+                sol.set_row_kernel(family)
+            bnds = pr.bounds_arrays(prob)
+            if extra.get("per_instance_bounds"):
+                bnds = tuple(np.broadcast_to(a, (B,) + a.shape).copy() for a in bnds)
+            sol.set_bounds(*bnds)
+            table = (rng.standard_normal((N + 9, nx)) * 0.1).astype(np.float32)
+            start = rng.integers(0, 9, size=B).astype(np.int32)
+            if nx <= 16 and not extra.get("per_instance_bounds"):
+                sol.set_xref_window(table, start)
+            else:
+                sol.set_xref(pr.expand_windows(table, start, N))
+            if extra.get("optional"):
+                sol.set_input_cost(prob["R"]); sol.set_coeff_d2p(np.zeros((nx, nu), np.float32) + 0.01); sol.set_uref(np.zeros((N - 1, nu), np.float32) + 0.02)
+                sol.set_optional_terms(True, True)
+            sol.set_x0(rng.uniform(-0.2, 0.2, size=(B, nx)).astype(np.float32))
+            sol.set_dispatch(1)
+            sol.solve(); sol.reset_dual_variables(); sol.solve(); sol.reset_workspace(); sol.set_x0(np.zeros((B, nx), np.float32) + 0.05); sol.solve()
+            names.add(sol.kernel_name())
+            if nx + nu <= 16 and variant in (2, 3) and not extra.get("optional"):
+                sol.mpc_run_async(3, 1 if nx <= 16 else 0); sol.synchronize()
+                if not extra.get("storage"):
+                    for fn in ("forward_pass", "update_slack", "update_dual", "update_linear_cost", "backward_pass_grad"):
+                        getattr(sol, fn)()
+            st = sol.get_state()
+            assert all(np.all(np.isfinite(st[k])) for k in STATE_ORDER), (sol.kernel_name(), B, "a NaN: an out-of-bounds read?")
+            assert tinympc.debug_check() == 0, (sol.kernel_name(), B, extra)
+            sol.close()
+        families = {n.split("<")[0] for n in names}
+        assert {"rowlane", "rowloop", "rowstream", "quadlane", "tile16", "wavestream", "waveres", "tile48", "stream", "generic"} <= families, families
+        # the checker itself: one word written just outside a work array must be counted
+        sol = tinympc.TinyBatchSolver(q30, 5)
+        for which in (0, 1):
+            sol._check(sol.lib.tiny_batch_debug_poke(sol._h, which))
+            assert tinympc.debug_check() == which + 1
+        sol.close()
+        assert tinympc.debug_check() == 0   # the damaged allocation is gone with its handle
+    finally:
+        tinympc.debug_guards(False)
+
+
 GENERIC_DIMS = [(20, 12, 12), (3, 2, 6), (8, 8, 6), (4, 3, 9), (36, 4, 5), (28, 16, 6)]
 
 
