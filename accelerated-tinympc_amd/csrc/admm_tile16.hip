@@ -855,10 +855,10 @@ bool tile16_supported(int nx, int nu, int N)
 
 int tile16_max_table_rows() { return TILE16_MAX_TABLE_ROWS; }
 
-hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t stream)
+hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t stream, int n_cu)
 {
     const int ntiles = (P.batch + 15) / 16;
-    static const int n_cu = []() { int dev = 0, n = 256; (void)hipGetDevice(&dev); hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; return n; }();
+    if (n_cu <= 0) n_cu = 256; // the caller passes the CU count of the handle's device
     const int want = (ntiles + TILE16_WAVES - 1) / TILE16_WAVES, nblocks = want < n_cu ? want : n_cu; // one persistent workgroup per CU
     const int rows = P.xref_mode == 1 ? P.table_rows : N;
     if (rows > TILE16_MAX_TABLE_ROWS) return hipErrorInvalidValue;

@@ -16,13 +16,16 @@ namespace tinympc
 // The sweep stops after the first kPredictorSteps horizon steps: under a stabilising feedback the rollout is farthest from
 // the box at the start of the horizon (on the bench workload the first two steps already order the groups as well as all
 // thirty do, tools/launch_tail.py), and the sweep is pure overhead.
-constexpr int kPredictorSteps = 8;
+constexpr int kPredictorSteps = 4; // (round 4: 8 -> 4, the same order on the bench workload, 4 us less in the timed step)
 
-template <int NX, int NU, bool H16>
-__global__ __launch_bounds__(WAVE) void dispatch_key_kernel(const RowParams P, float *__restrict__ key)
+// TILES: one workgroup of four waves per TILE of 16 instances (admm_tile16.hip) and key[] receives the tile's key — the largest of its four
+// groups' — directly (round 4: a separate kernel used to reduce the group keys, 5 us and a launch gap of the headline step)
+template <int NX, int NU, bool H16, bool TILES = false>
+__global__ __launch_bounds__(TILES ? 4 * WAVE : WAVE) void dispatch_key_kernel(const RowParams P, float *__restrict__ key)
 {
-    const int lane = threadIdx.x, r16 = lane & 15;
-    const int inst = blockIdx.x * 4 + (lane >> 4);
+    const int lane = threadIdx.x & (WAVE - 1), r16 = lane & 15;
+    const int grp = TILES ? (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6) : (int)blockIdx.x;
+    const int inst = grp * 4 + (lane >> 4);
     const bool valid = inst < P.batch;
     const int inst_a = valid ? inst : P.batch - 1; // padding rows of the last group read a valid instance
     const bool is_x = r16 < NX, is_u = (r16 >= NX) && (r16 < NX + NU);
@@ -47,16 +50,24 @@ __global__ __launch_bounds__(WAVE) void dispatch_key_kernel(const RowParams P, f
     pri = (valid && (is_x || is_u)) ? pri : 0.f;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) pri = fmaxf(pri, __shfl_xor(pri, m));
-    if (lane == 0) key[blockIdx.x] = pri;
+    if constexpr (TILES)
+    {
+        __shared__ float wk[4];
+        if (lane == 0) wk[threadIdx.x >> 6] = pri;
+        __syncthreads();
+        if (threadIdx.x == 0) key[blockIdx.x] = fmaxf(fmaxf(wk[0], wk[1]), fmaxf(wk[2], wk[3]));
+    }
+    else if (lane == 0) key[blockIdx.x] = pri;
 }
 
 // order[] = the n groups sorted by key, largest first: counting sort over 2 048 buckets = sign-less float bits >> 20 (exponent
 // and three mantissa bits; monotonic for the non-negative keys).  One workgroup; the order inside a bucket is arbitrary.
 constexpr int NBUCKET = 2048;
-__global__ __launch_bounds__(1024) void dispatch_order_kernel(const float *__restrict__ key, int *__restrict__ order, int n)
+__global__ __launch_bounds__(1024) void dispatch_order_kernel(const float *__restrict__ key, int *__restrict__ order, int n, int *__restrict__ counters)
 {
     __shared__ int cnt[NBUCKET], sa[NBUCKET], sb[NBUCKET];
     const int t = threadIdx.x;
+    if (t == 0 && counters) counters[0] = counters[1] = 0; // the solve kernel's unsolved count and tile queue (saves the memset node in front of this launch)
     auto bucket = [](float k) { return (int)((__builtin_bit_cast(unsigned, k) & 0x7fffffffu) >> 20); };
     for (int b = t; b < NBUCKET; b += 1024) cnt[b] = 0;
     __syncthreads();
@@ -82,34 +93,25 @@ __global__ __launch_bounds__(1024) void dispatch_order_kernel(const float *__res
     for (int g = t; g < n; g += 1024) order[atomicAdd(&dst[bucket(key[g])], 1)] = g;
 }
 
-// key of a tile of 16 instances (admm_tile16.hip) = the largest key of its four groups
-__global__ __launch_bounds__(256) void dispatch_tile_key_kernel(const float *__restrict__ key, float *__restrict__ tkey, int ngroups, int ntiles)
-{
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= ntiles) return;
-    float k = 0.f;
-    for (int j = 0; j < 4; j++)
-        if (4 * t + j < ngroups) k = fmaxf(k, key[4 * t + j]);
-    tkey[t] = k;
-}
-
-// tile != 0: order[] is a permutation of the ceil(batch/16) tiles of the 16-instances-per-wave kernel (key must have room for
-// ceil(batch/4) + ceil(batch/16) floats)
+// tile != 0: order[] is a permutation of the ceil(batch/16) tiles of the 16-instances-per-wave kernel
 hipError_t launch_dispatch_order(int nx, int nu, bool h16, const RowParams &P, float *key, int *order, hipStream_t stream, int tile)
 {
     const int ngroups = (P.batch + 3) / 4;
     const int ntiles = (P.batch + 15) / 16;
+    // (the sort also zeroes the two counters of the solve launch behind it: P.n_unsolved[0..1])
 #define TINY_KEY_DISPATCH(NX, NU)                                                                                      \
     if (nx == NX && nu == NU)                                                                                          \
     {                                                                                                                  \
-        if (h16) hipLaunchKernelGGL((dispatch_key_kernel<NX, NU, true>), dim3(ngroups), dim3(WAVE), 0, stream, P, key); \
-        else hipLaunchKernelGGL((dispatch_key_kernel<NX, NU, false>), dim3(ngroups), dim3(WAVE), 0, stream, P, key);   \
         if (tile)                                                                                                      \
         {                                                                                                              \
-            hipLaunchKernelGGL(dispatch_tile_key_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, stream, key, key + ngroups, ngroups, ntiles); \
-            hipLaunchKernelGGL(dispatch_order_kernel, dim3(1), dim3(1024), 0, stream, key + ngroups, order, ntiles);   \
+            if (h16) return hipErrorInvalidValue;                                                                      \
+            hipLaunchKernelGGL((dispatch_key_kernel<NX, NU, false, true>), dim3(ntiles), dim3(4 * WAVE), 0, stream, P, key); \
+            hipLaunchKernelGGL(dispatch_order_kernel, dim3(1), dim3(1024), 0, stream, key, order, ntiles, P.n_unsolved); \
+            return hipGetLastError();                                                                                  \
         }                                                                                                              \
-        else hipLaunchKernelGGL(dispatch_order_kernel, dim3(1), dim3(1024), 0, stream, key, order, ngroups);           \
+        if (h16) hipLaunchKernelGGL((dispatch_key_kernel<NX, NU, true>), dim3(ngroups), dim3(WAVE), 0, stream, P, key); \
+        else hipLaunchKernelGGL((dispatch_key_kernel<NX, NU, false>), dim3(ngroups), dim3(WAVE), 0, stream, P, key);   \
+        hipLaunchKernelGGL(dispatch_order_kernel, dim3(1), dim3(1024), 0, stream, key, order, ngroups, P.n_unsolved);  \
         return hipGetLastError();                                                                                      \
     }
     TINY_FOR_EACH_ROWDIMS(TINY_KEY_DISPATCH)

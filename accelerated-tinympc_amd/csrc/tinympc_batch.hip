@@ -152,8 +152,10 @@ __device__ __forceinline__ float get_elem(const float *src, long long i, int h16
 
 // host-layout src [cnt][nsteps][dim] (cnt = 1: shared by all instances)  ->  device layout, steps [step0, step0+nsteps)
 // of instances [0, nb).  Rows/instances beyond the source are left untouched (they were zeroed at allocation).
+// `mirror` (may be NULL): a plain copy of src, element for element — set_x0_device fills x.col(0) and the [B][nx] state buffer of the closed loop in
+// ONE launch (round 4: it was a device-to-device copy plus this kernel)
 __global__ void pack_kernel(const float *__restrict__ src, float *__restrict__ dst, int layout, Geo g, int fam, int nb,
-                            int shared, int step0, int nsteps, int h16)
+                            int shared, int step0, int nsteps, int h16, float *__restrict__ mirror = nullptr)
 {
     const int dim = fam ? g.nu : g.nx;
     const long long total = (long long)nb * nsteps * dim;
@@ -162,7 +164,9 @@ __global__ void pack_kernel(const float *__restrict__ src, float *__restrict__ d
         const int row = (int)(e % dim);
         const long long t = e / dim;
         const int s = (int)(t % nsteps), b = (int)(t / nsteps);
-        put_elem(dst, idx_of(layout, g, fam, b, step0 + s, row), src[((long long)(shared ? 0 : b) * nsteps + s) * dim + row], h16);
+        const float val = src[((long long)(shared ? 0 : b) * nsteps + s) * dim + row];
+        put_elem(dst, idx_of(layout, g, fam, b, step0 + s, row), val, h16);
+        if (mirror) mirror[e] = val;
     }
 }
 
@@ -339,6 +343,9 @@ struct TinyBatch
     bool derived_dirty[2] = {true, true};
     float *t_xref = nullptr, *t_bnd[4] = {};              // TILE derived
     float *r_xref = nullptr, *r_bounds = nullptr;         // ROW derived
+    size_t r_xref_n = 0, r_bounds_n = 0, r_uref_n = 0;    // their allocated sizes in floats (sized_buffer)
+    int graph_captures = 0;                               // closed-loop graphs captured so far (tiny_batch_debug_graph_captures)
+    int n_cu = 256;                                       // compute units of the handle's device
     float *tab_tile = nullptr, *tab_row = nullptr;        // trajectory table in both forms
     float *tab_row_h = nullptr;                           // ... and [rows][16] binary16 for fp16 storage
     int table_rows = 0;
@@ -405,6 +412,19 @@ int dev_alloc_zero(float **p, size_t nfloats)
     return 0;
 }
 
+// A derived input buffer of the ROW layout (reference, bounds table, Uref) is re-filled whenever its source changes; it is re-ALLOCATED only when its
+// size does: its address is a kernel argument baked into the captured closed-loop graph, and `set_xref; mpc_run(k)` in a loop must replay one graph
+// (round-3 advisor: with free + malloc per refill that held only while the allocator happened to return the same address)
+int sized_buffer(float **p, size_t *have, size_t nfloats)
+{
+    if (*p && *have == nfloats) return 0;
+    if (*p) { (void)guarded_free(*p); *p = nullptr; }
+    *have = 0;
+    TRY(dev_alloc_zero(p, nfloats));
+    *have = nfloats;
+    return 0;
+}
+
 float *work_ptr(TinyBatch *tb, int id) { return tb->layout == LAYOUT_ROW ? tb->pair[kPairOf[id]] : tb->arr[id]; }
 int h16_of(const TinyBatch *tb, int layout) { return (tb->h16 && layout == LAYOUT_ROW) ? 1 : 0; }
 // element type of one device array: the duals pair is fp32 under tiny_batch_set_storage_ex(16, 32)
@@ -433,11 +453,11 @@ void free_layout(TinyBatch *tb, int layout)
         for (int id = 0; id < TINY_ARR_COUNT; id++) { (void)guarded_free(tb->arr[id]); tb->arr[id] = nullptr; }
 }
 
-int launch_pack(TinyBatch *tb, const float *src, float *dst, int layout, int fam, int nb, bool shared, int step0, int nsteps)
+int launch_pack(TinyBatch *tb, const float *src, float *dst, int layout, int fam, int nb, bool shared, int step0, int nsteps, float *mirror = nullptr)
 {
     const long long total = (long long)nb * nsteps * (fam ? tb->nu : tb->nx);
     hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(256), 0, tb->stream, src, dst, layout, geo(tb), fam, nb,
-                       shared ? 1 : 0, step0, nsteps, h16_at(tb, layout, dst));
+                       shared ? 1 : 0, step0, nsteps, h16_at(tb, layout, dst), mirror);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -730,8 +750,7 @@ int prepare_inputs(TinyBatch *tb, int layout)
         if (!bounds_all_shared(tb)) // per-instance bounds: [bpad4][N][rw]{lo,hi}, built on the device from the canonical inputs
         {
             const size_t nf = (size_t)tb->bpad4 * N * RW * 2;
-            if (tb->r_bounds) { (void)guarded_free(tb->r_bounds); tb->r_bounds = nullptr; }
-            TRY(dev_alloc_zero(&tb->r_bounds, tb->h16 ? (nf + 1) / 2 : nf));
+            TRY(sized_buffer(&tb->r_bounds, &tb->r_bounds_n, tb->h16 ? (nf + 1) / 2 : nf));
             const InputArr *in = tb->in_bnd;
             hipLaunchKernelGGL(bounds_table_kernel, dim3(grid_for((long long)tb->batch * N * RW)), dim3(256), 0, tb->stream,
                                in[0].set ? in[0].dev : nullptr, in[1].set ? in[1].dev : nullptr, in[2].set ? in[2].dev : nullptr,
@@ -766,25 +785,24 @@ int prepare_inputs(TinyBatch *tb, int layout)
             for (size_t e = 0; e < tab.size(); e++) th[e] = (_Float16)tab[e];
             std::vector<float> packed((tab.size() + 1) / 2);
             std::memcpy(packed.data(), th.data(), packed.size() * sizeof(float));
-            if (tb->r_bounds) { (void)guarded_free(tb->r_bounds); tb->r_bounds = nullptr; }
+            TRY(sized_buffer(&tb->r_bounds, &tb->r_bounds_n, packed.size()));
             TRY(upload_vec(tb, &tb->r_bounds, packed));
         }
         else
         {
-            if (tb->r_bounds) { (void)guarded_free(tb->r_bounds); tb->r_bounds = nullptr; }
+            TRY(sized_buffer(&tb->r_bounds, &tb->r_bounds_n, tab.size()));
             TRY(upload_vec(tb, &tb->r_bounds, tab));
         }
         }
         const size_t nf = (size_t)(tb->in_xref.set && !tb->in_xref.shared ? tb->bpad4 : 1) * N * RW;
-        if (tb->r_xref) { (void)guarded_free(tb->r_xref); tb->r_xref = nullptr; }
-        TRY(dev_alloc_zero(&tb->r_xref, tb->h16 ? (nf + 1) / 2 : nf));
+        TRY(sized_buffer(&tb->r_xref, &tb->r_xref_n, tb->h16 ? (nf + 1) / 2 : nf));
+        if (!tb->in_xref.set) HIP_TRY(hipMemsetAsync(tb->r_xref, 0, tb->r_xref_n * sizeof(float), tb->stream)); // (a kept buffer of a reference since withdrawn)
         if (tb->in_xref.set)
             TRY(launch_pack(tb, tb->in_xref.dev, tb->r_xref, LAYOUT_ROW, 0, tb->in_xref.shared ? 1 : tb->batch, tb->in_xref.shared, 0, N));
-        if (tb->r_uref) { (void)guarded_free(tb->r_uref); tb->r_uref = nullptr; }
         if (tb->in_uref.set) // Uref on the u rows of an [inst][N][rw] array of its own (row N-1 and the x rows stay zero)
         {
             const size_t nu_f = (size_t)(tb->in_uref.shared ? 1 : tb->bpad4) * N * RW;
-            TRY(dev_alloc_zero(&tb->r_uref, tb->h16 ? (nu_f + 1) / 2 : nu_f));
+            TRY(sized_buffer(&tb->r_uref, &tb->r_uref_n, tb->h16 ? (nu_f + 1) / 2 : nu_f));
             TRY(launch_pack(tb, tb->in_uref.dev, tb->r_uref, LAYOUT_ROW, 1, tb->in_uref.shared ? 1 : tb->batch, tb->in_uref.shared, 0, N - 1));
         }
     }
@@ -872,14 +890,17 @@ bool tile16_applies(const TinyBatch *tb)
 
 // auto between the two state-on-chip kernels of the nx = 32 class, by rounds of the launch (measured on the 256 CUs of an MI355X,
 // bench workload: one round of the wave kernel = 2 048 instances = 5.0 ms, one round of the tile kernel = 4 096 instances = 7.2 ms;
-// 2 048: 5.4 against 7.1 ms, 2 304: 8.9 / 7.1, 4 096: 10.1 / 7.4, 4 352: 13.4 / 14.9, 6 144: 15.0 / 14.4, 16 384: 37.5 / 28.6)
-bool tile48_pays(int batch)
+// 2 048: 5.4 against 7.1 ms, 2 304: 8.9 / 7.1, 4 096: 10.1 / 7.4, 4 352: 13.4 / 14.9, 6 144: 15.0 / 14.4, 16 384: 37.5 / 28.6; round 4: tile48 27.6)
+bool tile48_pays(int batch, int n_cu)
 {
-    static const int n_cu = []() { int dev = 0, n = 256; (void)hipGetDevice(&dev); hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; return n; }();
     const long slots_w = 8L * n_cu, slots_t = 16L * n_cu; // resident instances: two waves per SIMD / one workgroup of sixteen per CU
     if (batch <= slots_w) return false;
     const long rounds_w = (batch + slots_w - 1) / slots_w, rounds_t = (batch + slots_t - 1) / slots_t;
-    return rounds_t * 7.2 <= rounds_w * 5.0 * 0.93; // (the wave kernel's last, partly filled round overlaps the one before)
+    // a launch costs its rounds; ONE ratio carries the comparison (round 4: it used to be two absolute times of one workload): a round of the tile kernel
+    // (sixteen instances per CU) takes 1.42 rounds of the wave kernel (eight per CU) — 6.9 against 4.85 ms at N = 50 on the MI355X, and the two scale
+    // alike with the horizon and the iteration count; the wave kernel's last, partly filled round overlaps the one before (x 0.93)
+    constexpr double kTileRoundInWaveRounds = 1.42;
+    return rounds_t * kTileRoundInWaveRounds <= rounds_w * 0.93;
 }
 
 int row_family(const TinyBatch *tb)
@@ -889,7 +910,7 @@ int row_family(const TinyBatch *tb)
     if (tb->wave_ok)
     {
         if (tb->row_family_forced == 3) return 3;
-        if (tb->tile48_ok && !tb->h16 && (tb->row_family_forced == 7 || (tb->row_family_forced < 0 && tile48_pays(tb->batch)))) return 7;
+        if (tb->tile48_ok && !tb->h16 && (tb->row_family_forced == 7 || (tb->row_family_forced < 0 && tile48_pays(tb->batch, tb->n_cu)))) return 7;
         return tb->waveres_ok ? 6 : 3;
     }
     // per-instance bounds: the unrolled register-resident kernel (fp32 storage) and the rolled-loop ones (N <= 64, either storage)
@@ -1059,12 +1080,13 @@ constexpr int kDispatchMinGroups = 4096; // two rounds of waves on 256 CUs x 4 S
 int enqueue_solve(TinyBatch *tb, int v, bool record_events)
 {
     const int layout = tile_variant(v) ? LAYOUT_TILE : LAYOUT_ROW;
-    HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, 2 * sizeof(int), tb->stream)); // [0] unsolved count, [1] tile queue of admm_tile16.hip
     // longest-first dispatch (dispatch_order.hip): predictor sweep + bucket sort ahead of the register-resident 16-lane kernels;
     // pays off only when the launch is several rounds of waves deep
     const int fam_l = layout == LAYOUT_ROW ? row_family(tb) : -1;
     const bool predicted_order = layout == LAYOUT_ROW && tb->dispatch_mode == 1 && !tb->order_dev && (fam_l == 0 || fam_l == 1 || fam_l == 5) && !tb->dual32 &&
                                  tb->bpad4 / 4 >= kDispatchMinGroups && tb->max_iter > 1;
+    // [0] unsolved count, [1] tile queue of admm_tile16.hip: zeroed by the sort kernel of the predicted order where that runs (one stream node less)
+    if (!predicted_order) HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, 2 * sizeof(int), tb->stream));
     if (predicted_order)
     {
         RowParams K;
@@ -1113,7 +1135,7 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
             : fam == 1 ? launch_admm_rowloop(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
             : fam == 3 ? launch_admm_wavestream(tb->nx, tb->nu, P, tb->stream)
             : fam == 4 ? launch_admm_quadlane(tb->N, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
-            : fam == 5 ? launch_admm_tile16(tb->N, v == VAR_ROW_EXACT, P, tb->stream)
+            : fam == 5 ? launch_admm_tile16(tb->N, v == VAR_ROW_EXACT, P, tb->stream, tb->n_cu)
             : fam == 6 ? launch_admm_waveres(tb->nx, tb->nu, v == VAR_ROW_EXACT, P, tb->stream)
             : fam == 7 ? launch_admm_tile48(tb->N, v == VAR_ROW_EXACT, P, tb->stream)
                        : launch_admm_rowstream(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream);
@@ -1214,6 +1236,10 @@ int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int dev
     tb->layout = (row_ok || wave_ok || !tile_ok) ? LAYOUT_ROW : LAYOUT_TILE;
     auto cleanup = [&](int rc) { tiny_batch_destroy(tb); return rc; };
     if (hipSetDevice(device) != hipSuccess) return cleanup(fail(TINY_BATCH_EHIP, "hipSetDevice(%d) failed", device));
+    {
+        int ncu = 0; // of THIS handle's device (round-3 advisor: a process-wide static used to cache whichever device was current first)
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) tb->n_cu = ncu;
+    }
     if (int rc = alloc_layout(tb, tb->layout)) return cleanup(rc);
     if (int rc = dev_alloc_zero(&tb->res, (size_t)batch * 4)) return cleanup(rc);
     if (int rc = dev_alloc_zero((float **)&tb->status, batch)) return cleanup(rc);
@@ -1387,8 +1413,7 @@ int tiny_batch_set_x0_device(TinyBatch *tb, const float *d_x0)
     CHECK_TB(tb); CHECK_PTR(d_x0);
     TRY(set_device(tb));
     tb->x0_zero_pending = false; // all of x.col(0) and x0buf is overwritten
-    HIP_TRY(hipMemcpyAsync(tb->x0buf, d_x0, (size_t)tb->batch * tb->nx * sizeof(float), hipMemcpyDeviceToDevice, tb->stream));
-    return launch_pack(tb, d_x0, work_ptr(tb, TINY_ARR_X), tb->layout, 0, tb->batch, false, 0, 1);
+    return launch_pack(tb, d_x0, work_ptr(tb, TINY_ARR_X), tb->layout, 0, tb->batch, false, 0, 1, tb->x0buf); // x.col(0) and the state buffer in one launch
 }
 
 int tiny_batch_set_xref(TinyBatch *tb, const float *xref, int shared)
@@ -1737,7 +1762,7 @@ int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, 
         tb->last_dispatch = P.order ? 2 : 0;
         HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, 2 * sizeof(int), tb->stream)); // [0] unsolved count, [1] tile queue of admm_tile16.hip
         hipError_t e = fam == 0   ? launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, false, P, tb->stream)
-                       : fam == 5 ? launch_admm_tile16(tb->N, v == VAR_ROW_EXACT, P, tb->stream)
+                       : fam == 5 ? launch_admm_tile16(tb->N, v == VAR_ROW_EXACT, P, tb->stream, tb->n_cu)
                                   : launch_admm_quadlane(tb->N, v == VAR_ROW_EXACT, false, P, tb->stream);
         if (e != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
         if (d_u0_traj) TRY(launch_unpack(tb, work_ptr(tb, TINY_ARR_U), d_u0_traj + (size_t)(steps - 1) * u0n, tb->layout, 1, tb->batch, 0, 1));
@@ -1783,6 +1808,7 @@ int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, 
         (void)hipGraphDestroy(graph);
         HIP_TRY(ei);
         tb->graph_sig = sig;
+        tb->graph_captures++;
     }
     HIP_TRY(hipGraphLaunch(tb->graph_exec, tb->stream));
     tb->duals_zero_pending = tb->cold_pending = false;
@@ -1851,6 +1877,12 @@ const char *tiny_batch_kernel_name(TinyBatch *tb)
     return tb->kname.c_str();
 }
 
+int tiny_batch_debug_graph_captures(TinyBatch *tb)
+{
+    CHECK_TB(tb);
+    return tb->graph_captures; // how often tiny_batch_mpc_run_* had to capture its hipGraph (a replay does not count)
+}
+
 int tiny_batch_debug_guards(int on)
 {
     std::lock_guard<std::mutex> lk(g_guard_mu);
@@ -1901,6 +1933,21 @@ int tiny_batch_arithmetic(TinyBatch *tb)
     int v = 0;
     TRY(resolve_variant(tb, &v));
     return (v == VAR_ROW_EXACT || v == VAR_GENERIC) ? TINY_BATCH_ARITH_EXACT : TINY_BATCH_ARITH_FMA;
+}
+
+// the kernel a closed-loop run of several steps (tiny_batch_mpc_run_async) launches: it can differ from the kernel of a lone solve (the automatic
+// choice keeps the 16-lane kernel's on-chip MPC loop where a lone solve of the same batch goes to the matrix-core kernel)
+const char *tiny_batch_closed_loop_kernel_name(TinyBatch *tb)
+{
+    if (!tb) return "";
+    static thread_local std::string name;
+    const bool keep = tb->closed_loop_run;
+    tb->closed_loop_run = true;
+    update_kname(tb);
+    name = tb->kname;
+    tb->closed_loop_run = keep;
+    update_kname(tb);
+    return name.c_str();
 }
 
 int tiny_batch_set_row_kernel(TinyBatch *tb, int family)

@@ -139,7 +139,7 @@ hipError_t launch_admm_quadlane(int N, bool exact, bool h16, const RowParams &P,
 // sixteen-instances-per-wave register-resident kernel with the products on the matrix cores (admm_tile16.hip): nx = 12, nu = 4,
 // instantiated horizons; ROW layout and RowParams of the row kernels; shared bounds, window / shared reference, fp32 storage
 bool tile16_supported(int nx, int nu, int N);
-hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t stream);
+hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t stream, int n_cu);
 int tile16_max_table_rows(); // rows of a trajectory table that fit the kernel's LDS share
 
 // wave-per-instance exact kernel (admm_wave.hip): 16 < nx + nu <= 64, any N, state in HBM, row width 64

@@ -74,7 +74,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch_mpc_step_async": [P, C.c_int], "tiny_batch_get_x0": [P, F],
         "tiny_batch_mpc_run_async": [P, C.c_int, C.c_int], "tiny_batch_mpc_run_traj_async": [P, C.c_int, C.c_int, P], "tiny_batch_mpc_run_traj": [P, C.c_int, C.c_int, F],
         "tiny_batch_enable_timing": [P, C.c_int], "tiny_batch_last_solve_ms": [P, F],
-        "tiny_batch_select_kernel": [P, C.c_int], "tiny_batch_arithmetic": [P], "tiny_batch_set_storage": [P, C.c_int], "tiny_batch_set_storage_ex": [P, C.c_int, C.c_int],
+        "tiny_batch_select_kernel": [P, C.c_int], "tiny_batch_arithmetic": [P], "tiny_batch_debug_graph_captures": [P], "tiny_batch_set_storage": [P, C.c_int], "tiny_batch_set_storage_ex": [P, C.c_int, C.c_int],
         "tiny_batch_set_row_kernel": [P, C.c_int],
         "tiny_batch_set_dispatch": [P, C.c_int], "tiny_batch_set_dispatch_order_device": [P, P], "tiny_batch_dispatch_applied": [P],
         "tiny_batch_set_optional_terms": [P, C.c_int, C.c_int], "tiny_batch_set_input_cost": [P, F],
@@ -115,6 +115,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
     lib.tiny_batch_destroy.argtypes, lib.tiny_batch_destroy.restype = [P], None
     lib.tiny_batch_last_error.argtypes, lib.tiny_batch_last_error.restype = [], C.c_char_p
     lib.tiny_batch_kernel_name.argtypes, lib.tiny_batch_kernel_name.restype = [P], C.c_char_p
+    lib.tiny_batch_closed_loop_kernel_name.argtypes, lib.tiny_batch_closed_loop_kernel_name.restype = [P], C.c_char_p
     _lib = lib
     return lib
 
@@ -380,6 +381,9 @@ class TinyBatchSolver:
 
     def kernel_name(self) -> str:
         return self.lib.tiny_batch_kernel_name(self._h).decode()
+
+    def closed_loop_kernel_name(self) -> str:
+        return self.lib.tiny_batch_closed_loop_kernel_name(self._h).decode()
 
     def arithmetic(self) -> str:
         """tiny_batch_arithmetic: "exact" (bitwise the reference) or "fma" for what the next solve computes in; raises where no kernel would

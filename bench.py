@@ -513,7 +513,7 @@ def main():
             sol.synchronize()
             dt_c = time.perf_counter() - t_c
             itc, stc, _ = sol.get_status()
-            closed = {"kernel": sol.kernel_name(), "mpc_steps": ksteps, "ms_per_mpc_step": dt_c / ksteps * 1e3, "solves_per_s": B * ksteps / dt_c,
+            closed = {"kernel": sol.closed_loop_kernel_name(), "mpc_steps": ksteps, "ms_per_mpc_step": dt_c / ksteps * 1e3, "solves_per_s": B * ksteps / dt_c,
                       "mean_iters_last_step": float(itc.mean()), "frac_converged_last_step": float(np.mean(stc == 1)),
                       "note": "warm-started tracking loop on the device (tiny_batch_mpc_run_async: one launch, state on chip between solves), wall time"}
             # the same loop forced onto the headline kernel, whose MPC loop stays on chip too (round 4): for the record — sixteen instances in
@@ -525,7 +525,7 @@ def main():
                 sol.set_xref_window(table, gstart[lo:hi])
                 sol.mpc_run_async(ksteps, 1)
                 sol.synchronize()
-                k16 = sol.kernel_name()
+                k16 = sol.closed_loop_kernel_name()
                 t_c = time.perf_counter()
                 sol.mpc_run_async(ksteps, 1)
                 sol.synchronize()

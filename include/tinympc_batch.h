@@ -191,6 +191,9 @@ extern "C"
     /* Name of the kernel variant the next solve will launch ("rowlane<12,4,30,exact>", "rowstream<12,4,fast>",
      * "stream<3,1>", with ",h16" appended under fp16 storage). */
     const char *tiny_batch_kernel_name(TinyBatch *tb);
+    /* ... and of the kernel a closed-loop run of several steps (tiny_batch_mpc_run_async) launches, which can differ: the automatic choice
+     * keeps the 16-lane kernel, whose MPC loop stays on chip, where a lone solve of the same batch goes to the matrix-core kernel. */
+    const char *tiny_batch_closed_loop_kernel_name(TinyBatch *tb);
     /* Debug guard zones (the stand-in for a GPU address sanitizer, which this platform does not offer).
      * tiny_batch_debug_guards(1): every device allocation this library makes FROM NOW ON carries 1 KB of quiet-NaN guard words at
      * both ends (handles created before keep what they have).  tiny_batch_debug_check() waits for the device and returns the number of
@@ -198,6 +201,8 @@ extern "C"
      * READ returns NaN and surfaces in the results.  The kernels are the shipped ones.  tiny_batch_debug_poke writes one word just
      * outside a work array of a guarded handle (which = 0 in front, 1 behind): the self-test of the checker. */
     int tiny_batch_debug_guards(int on);
+    /* How often tiny_batch_mpc_run_* captured a hipGraph for this handle so far (replays of a captured graph do not count): a test hook. */
+    int tiny_batch_debug_graph_captures(TinyBatch *tb);
     long long tiny_batch_debug_check(void);
     int tiny_batch_debug_poke(TinyBatch *tb, int which);
     /* The ARITHMETIC the next solve computes in — the contract behind the kernel name:
@@ -264,7 +269,10 @@ extern "C"
     int tiny_batch_dispatch_applied(TinyBatch *tb);
     /* The caller's own order (e.g. from the iteration counts of the previous MPC step): d_order is a device array holding a
      * permutation of the ceil(batch/4) group indices, workgroup b solves instances 4*d_order[b] .. +3; it must stay valid
-     * until the solves that use it have finished.  NULL returns to tiny_batch_set_dispatch's mode. */
+     * until the solves that use it have finished.  NULL returns to tiny_batch_set_dispatch's mode.  The order lists groups of FOUR
+     * instances: it applies to the kernels that solve four instances per wave (unrolled and rolled 16-lane kernels); the
+     * 16-instances-per-wave kernel (tile16) ignores it when forced, and the automatic choice stays off tile16 while an order is set
+     * (tiny_batch_dispatch_applied() says what a launch did). */
     int tiny_batch_set_dispatch_order_device(TinyBatch *tb, const int *d_order);
 
     /* ---- the two terms the reference ships commented out, off by default ----

@@ -1810,6 +1810,30 @@ def test_device_closed_loop_equals_reference_trace(tinympc, oracle_mod, name, va
     b.close()
 
 
+def test_mpc_run_replays_one_graph_while_only_buffer_contents_change(tinympc):
+    """`set_xref; mpc_run(k)` in a loop must replay ONE captured hipGraph: the derived reference / bounds buffers keep their address while their
+    size does not change (round-3 advisor: they used to be freed and re-allocated on every refill, so the replay depended on the allocator
+    handing the same address back).  tiny_batch_debug_graph_captures counts the captures."""
+    pr = tinympc.problems
+    prob = pr.quadrotor(20, 17)   # a class whose closed loop runs from a graph (rolled-loop kernel)
+    B = 33
+    x0, table, start = pr.tracking_batch(B, 17, seed=2)
+    rng = np.random.default_rng(0)
+    sol = tinympc.TinyBatchSolver(prob, B)
+    sol.set_bounds(*pr.bounds_arrays(prob)); sol.set_x0(x0)
+    caps = lambda: sol.lib.tiny_batch_debug_graph_captures(sol._h)
+    for k in range(6):
+        sol.set_xref((rng.standard_normal((B, 17, 12)) * 0.1).astype(np.float32))   # new CONTENTS, same shape
+        if k == 3:
+            sol.set_bounds(*[b * np.float32(0.9) for b in pr.bounds_arrays(prob)])   # same for the bounds table
+        sol.mpc_run_async(3, 0); sol.synchronize()
+        assert caps() == 1, (k, caps())
+    sol.set_xref((rng.standard_normal((17, 12)) * 0.1).astype(np.float32))           # per-instance -> shared: another stride, another graph
+    sol.mpc_run_async(3, 0); sol.synchronize()
+    assert caps() == 2
+    sol.close()
+
+
 @pytest.mark.parametrize("variant_name", ["loop_exact", "rowstream_exact", "stream"])
 def test_mpc_run_graph_is_rebuilt_when_its_arguments_change(tinympc, variant_name):
     """The hipGraph that tiny_batch_mpc_run_async replays carries rho, the bound flags and the reference strides as kernel
@@ -2575,7 +2599,7 @@ def test_fp64_vs_oracle(tinympc, oracle_mod, nx, nu, N, kernel):
 # ---------------------------------------------------------------------------------------------------------------------
 # one node, several GPUs, from C++ through the C-ABI (one host thread, one handle + stream per device)
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,devices", [(4096, "0,0"), (1000, "0,0,0"), (37, "0,0"), (40000, "0,0")])
+@pytest.mark.parametrize("B,devices", [(4096, "0,0"), (1000, "0,0,0"), (37, "0,0"), (40000, "0,0"), (40000, "all")])
 def test_cpp_multi_device_example_equals_the_single_handle_solve(tinympc, tmp_path, B, devices):
     """examples/quadrotor_tracking_multigpu.cpp: the batch block-sharded over several handles (one per listed device; on a
     one-GPU box two or three handles on device 0, which exercises the same code: per-handle set_device, group solve, the
@@ -2587,6 +2611,12 @@ def test_cpp_multi_device_example_equals_the_single_handle_solve(tinympc, tmp_pa
     root = Path(__file__).resolve().parents[1]
     if shutil.which("g++") is None:
         pytest.skip("no g++")
+    if devices == "all":   # DISTINCT devices: the peer-copy branch of tiny_batch_group_gather_u0 (round-3 advisor); needs more than one GPU
+        import torch
+        n = torch.cuda.device_count()
+        if n < 2:
+            pytest.skip("one GPU here: the cross-device branch runs where the driver has a multi-GPU node")
+        devices = ",".join(str(d) for d in range(min(n, 6)))
     lib_dir = root / "accelerated-tinympc_amd" / "lib"
     exe = tmp_path / "multigpu"
     r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", f"-I{root / 'include'}", str(root / "examples" / "quadrotor_tracking_multigpu.cpp"),
