@@ -254,7 +254,7 @@ def main():
                     help="workgroup dispatch order of the row kernel: 0 index order, 1 longest first by the predicted iteration count "
                          "(tiny_batch_set_dispatch; the predictor sweep and the sort run inside the timed region)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and with it the parity sample)")
-    ap.add_argument("--no-closed-loop", action="store_true", help="skip the warm-started closed-loop and the pipelined-batches extras (profiling runs: "
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the fixed10 / transfers legs and the warm-started closed-loop and pipelined-batches extras (profiling runs: "
                     "its launches of the same kernel would be averaged into the per-kernel statistics)")
     args = ap.parse_args()
 
@@ -415,7 +415,7 @@ def main():
     # arithmetic, same inputs, ten iterations for every instance; and the H2D / D2H legs of a host-driven step (x0 up, u.col(0) down),
     # hipEvent-timed on pinned buffers.  Extras of rank 0: neither enters `value`.
     fixed10 = transfers = None
-    if rank == 0 and world == 1 and args.mode == "early_exit":
+    if rank == 0 and world == 1 and args.mode == "early_exit" and not args.no_closed_loop:   # (profiling runs skip it: the same kernel on another workload)
         try:
             sol.set_settings(**dict(settings, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=10))
             for _ in range(2):
