@@ -33,7 +33,9 @@ pr = T.problems
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 CLASSES = [("quad", 30), ("quad", 25), ("quad", 20), ("quad", 10), ("quad", 17), ("quad", 7), ("quad", 36), ("quad", 40), ("quad", 50), ("quad", 61), ("quad", 67), ("cartpole", 10),
-           ("cartpole", 23), ("odd", 7), ("odd", 13), ("rand32", 50), ("rand32", 50), ("rand32", 23), ("rand32", 2), ("r8_4", 9), ("r12_2", 14), ("r4_2", 8), ("r4_4", 35), ("w16_8", 10), ("w16_4", 12), ("w20_8", 11), ("w24_4", 9)]
+           ("cartpole", 23), ("odd", 7), ("odd", 13), ("rand32", 50), ("rand32", 50), ("rand32", 23), ("rand32", 2), ("r8_4", 9), ("r12_2", 14), ("r4_2", 8), ("r4_4", 35), ("w16_8", 10), ("w16_4", 12), ("w20_8", 11), ("w24_4", 9),
+           # round 4: classes outside the compiled lists, solved by the run-time-dimension exact kernel (admm_generic.hip)
+           ("g20_12", 12), ("g3_2", 6), ("g8_8", 6), ("g4_3", 9), ("g36_4", 5), ("g28_16", 6)]
 if len(sys.argv) > 3:   # optional third argument: only the classes whose name contains it (e.g. "rand32": the nx = 32 kernels incl. tile48)
     CLASSES = [c for c in CLASSES if sys.argv[3] in c[0]]
 t_end, rounds, solves, t_note, overflowed, refused = time.time() + budget, 0, 0, time.time(), 0, 0
@@ -48,7 +50,8 @@ while time.time() < t_end:
         prob = {"quad": lambda: pr.quadrotor(20, N), "cartpole": lambda: pr.cartpole(N), "odd": lambda: pr.random_system(8, 3, N, seed=99),
                 "rand32": lambda: pr.random_system(32, 16, N)}[kind]()
     nx, nu = prob["nx"], prob["nu"]
-    wave = kind == "rand32" or kind.startswith("w")
+    gen = kind.startswith("g")   # no compiled kernel: generic<nx,nu,exact>
+    wave = kind == "rand32" or kind.startswith("w") or gen
     B = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 200])) if not wave else int(rng.choice([1, 3, 9, 17, 40]))
     settings = dict(abs_pri_tol=float(rng.choice([0.0, 1e-3, 1e-2, 0.5])), abs_dua_tol=float(rng.choice([0.0, 1e-3, 1e-1, 5.0])),
                     max_iter=int(rng.choice([0, 1, 2, 3, 7, 20, 45])), check_termination=int(rng.choice([1, 1, 2, 3, 7])),
@@ -75,6 +78,8 @@ while time.time() < t_end:
             except T.TinyBatchError:
                 pass
     R = O.round_h16 if h16 else (lambda a: a)
+    if not wave and not h16 and rng.random() < 0.06:   # the same kernel forced onto a compiled class (variant 4)
+        sol.select_kernel(4); gen = True
     fams = [0] + ([1, 2, 3, 4, 5] if not wave else [6, 7, 8, 8])   # 5 = tile16 (MFMA products), 6 / 7 = streaming / on-chip wave kernel, 8 = tile48 (nx = 32)
     fam = int(rng.choice(fams))
     try:
@@ -106,7 +111,7 @@ while time.time() < t_end:
     else:
         x0 = rng.uniform(-0.5, 0.5, size=(B, nx)).astype(np.float32)
         st["x"][:, 0] = R(x0); sol.set_x0(x0)
-    opt = (rng.integers(2), rng.integers(2)) if (nx + nu <= 16 and rng.random() < 0.17) else (0, 0)
+    opt = (rng.integers(2), rng.integers(2)) if (nx + nu <= 16 and not gen and rng.random() < 0.17) else (0, 0)
     if opt[0] or opt[1]:   # the commented-out terms: any combination, shared or per-instance Uref, zeros and negative zeros in it
         prob = dict(prob, coeff_d2p=(rng.standard_normal((nx, nu)) * 0.05).astype(np.float32), R=rng.uniform(0.2, 3.0, nu).astype(np.float32))
         uref = (rng.standard_normal((N - 1, nu) if rng.random() < 0.5 else (B, N - 1, nu)) * 0.2).astype(np.float32)
@@ -156,7 +161,7 @@ while time.time() < t_end:
                     print("   ", idx, "gpu", got[name][idx], "oracle", st[name][idx], "iter gpu/oracle", got["iter"][idx[0]], st["iter"][idx[0]])
                 sys.exit(1)
     finite = all(np.all(np.isfinite(st[n_])) for n_ in O.STATE_ORDER)
-    if finite and nx + nu <= 16 and not h16d and rng.random() < 0.3:   # one of the six step functions on the state the chain left
+    if finite and nx + nu <= 16 and not h16d and not gen and rng.random() < 0.3:   # one of the six step functions on the state the chain left
         fn = O.Oracle.STEP_FUNCTIONS[rng.integers(6)]
         ref_rv = orc.step(fn, st, *bnds, xref)
         rv = getattr(sol, fn)()
