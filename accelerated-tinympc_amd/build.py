@@ -17,7 +17,7 @@ CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libtinympc_hip.so"
 WRAPPER_LIB = PKG / "lib" / "libtinympc_wrapper.so"  # same-name twin of the reference's generated wrapper library
 WRAPPER64_LIB = PKG / "lib" / "libtinympc_wrapper64.so"  # the native names (tiny_solve, forward_pass, ...) for tinytype = double
-SOURCES = ["tinympc_batch.hip", "tinympc_batch64.hip", "admm_stream.hip", "admm_generic.hip", "admm_rowlane.hip", "admm_rowloop.hip", "admm_quadlane.hip", "admm_tile16.hip", "admm_wave.hip", "admm_waveres.hip", "admm_tile48.hip", "admm_steps.hip", "dispatch_order.hip", "riccati.cpp"]
+SOURCES = ["tinympc_batch.hip", "tinympc_batch64.hip", "admm_stream.hip", "admm_generic.hip", "admm_rowlane.hip", "admm_rowloop.hip", "admm_quadlane.hip", "admm_tile16.hip", "admm_tile16_pi.hip", "admm_wave.hip", "admm_waveres.hip", "admm_tile48.hip", "admm_steps.hip", "dispatch_order.hip", "riccati.cpp"]
 WRAPPER_SRCS = [CSRC / "wrapper_compat.cpp", CSRC / "admm_compat.cpp"]
 HEADERS = [CSRC / "tinympc_internal.h", CSRC / "rowlane_math.h", CSRC / "tile_math.h", CSRC / "wave_math.h", CSRC / "dpp_ops_gen.h", PKG.parent / "include" / "tinympc_batch.h", PKG.parent / "include" / "tinympc_batch64.h"]
 # -ffp-contract=off : exact arithmetic must not fuse a*b+c; the fast paths call fma explicitly
@@ -27,10 +27,13 @@ HEADERS = [CSRC / "tinympc_internal.h", CSRC / "rowlane_math.h", CSRC / "tile_ma
 # 1.88 -> 1.79 ms, the other kernels do not react to it); MFMA results go to VGPRs (the sums that consume the exact products are VALU instructions,
 # which cannot read the accumulator half of the register file: left to its heuristics hipcc parks the products there and
 # copies every one of them back, 110 v_accvgpr_read per horizon step)
-EXTRA_FLAGS = {"admm_tile16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"] + os.environ.get("TINYMPC_T16_FLAGS", "").split(),
+_T16_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"] + os.environ.get("TINYMPC_T16_FLAGS", "").split()
+EXTRA_FLAGS = {"admm_tile16.hip": _T16_FLAGS, "admm_tile16_pi.hip": _T16_FLAGS,
                "admm_rowlane.hip": os.environ.get("TINYMPC_ROWLANE_FLAGS", "").split(),
                "admm_waveres.hip": os.environ.get("TINYMPC_WAVERES_FLAGS", "").split(),
                "admm_tile48.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"] + os.environ.get("TINYMPC_T48_FLAGS", "").split()}
+# translation units that #include another kernel source: rebuilt with it
+INCLUDED_SOURCES = {"admm_tile16_pi.hip": ["admm_tile16.hip"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-gpu-rdc"]
 
 
@@ -55,7 +58,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     hdr_t = max(h.stat().st_mtime for h in HEADERS + [Path(__file__)] if h.exists())
     procs = []
     for src, obj in _objs():
-        if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_t):
+        src_t = max([src.stat().st_mtime] + [(CSRC / i).stat().st_mtime for i in INCLUDED_SOURCES.get(src.name, [])])
+        if not force and obj.exists() and obj.stat().st_mtime > max(src_t, hdr_t):
             continue
         cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
         if verbose:
@@ -90,7 +94,7 @@ def device_asm(source: str) -> Path:
     src = CSRC / source
     out = PKG / "lib" / "asm" / (Path(source).stem + ".s")
     out.parent.mkdir(parents=True, exist_ok=True)
-    newest = max(d.stat().st_mtime for d in [src, Path(__file__), *HEADERS] if d.exists())
+    newest = max(d.stat().st_mtime for d in [src, Path(__file__), *HEADERS, *[CSRC / i for i in INCLUDED_SOURCES.get(source, [])]] if d.exists())
     if not out.exists() or out.stat().st_mtime < newest:
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         cmd = [hipcc, *[f for f in FLAGS if f != "-fPIC"], *EXTRA_FLAGS.get(source, []), "-S", "--cuda-device-only", str(src), "-o", str(out)]
@@ -153,6 +157,8 @@ def device_isa_sha(source: str) -> str:
 def kernel_isa_sha(kernel_name: str) -> str | None:
     """device_isa_sha of the translation unit behind a kernel name such as 'tile16<12,4,30,exact>'; None for an unknown family or a missing object."""
     src = KERNEL_SOURCES.get(kernel_name.split("<", 1)[0])
+    if src == "admm_tile16.hip" and kernel_name.endswith(",pi>"):
+        src = "admm_tile16_pi.hip"  # the per-instance instantiations are a translation unit of their own
     try:
         return device_isa_sha(src) if src else None
     except (OSError, AssertionError, KeyError):

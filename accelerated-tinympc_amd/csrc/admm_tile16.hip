@@ -362,14 +362,65 @@ __device__ __forceinline__ f32x4 lin_cost4(const f32x4 &cq, const f32x4 &rho4, c
 constexpr int TILE16_WAVES = 4;         // waves per workgroup = one per SIMD of a CU; they share the bounds and reference tables
 constexpr int TILE16_MAX_TABLE_ROWS = 512;
 
+// ---- BR / XR = true (round 4, the "pi" instantiations): box bounds (BR) and / or the reference (XR) PER INSTANCE (types.hpp:88-92: every
+// reference workspace owns its u_min .. x_max and its Xref).  The kernel has no register to prefetch them into (512 of 512 in use) and the
+// 61 KB + 30 KB a tile would need do not fit LDS beside the slack, so the rows travel HBM/L2 -> LDS by LDS-DMA (`global_load_lds_dwordx4`: no
+// VGPR destination) into per-wave slots:
+//   * lane (g, c) fetches 16-byte piece g of instance c's 64-byte reference row (for the 128-byte {lo, hi} row: pieces 2g and 2g + 1), so whole
+//     rows are fetched, four lanes each; piece g of instance c lands lane-linear at slot + 16 (16 g + c);
+//   * lane (g', c) then reads element 4 v + g' of ITS instance from slot + 256 v + 16 c + 4 g' (banks 4 c + g': conflict free) — the same
+//     registers the shared tables deliver, so the arithmetic is untouched (tools/micro/glds_ring.hip checks the mapping, a destination above
+//     64 KB in M0 and the counted waits in isolation);
+//   * a table that does not change along the horizon (RowParams::pi_flags bit clear: the usual case — every robot its own limits, its own
+//     set point) is ONE row per instance: fetched once per tile into a single slot, nothing moves inside the iteration loop;
+//   * a table that does (bit set) goes through a ring of three step slots, two steps ahead of its use, retired with counted `s_waitcnt vmcnt`;
+//     a slot is refilled only after the values read from it have been consumed (the DMA statement takes one of them as an operand).  A
+//     DMA costs a lone wave about 30 clocks of issue (M0, one wait state, the instruction): three per step pair are 8 % of it.
+// The other table of a BR-only / XR-only instantiation is the batch-shared one staged in LDS, as in the base kernel.  hipcc does not count an
+// asm DMA in its own s_waitcnt bookkeeping; the iteration loop issues no other vector memory instruction, and a foreign entry in the
+// in-order counter can only make either side's counted wait longer, never shorter.  M0 is written by these statements only
+// (tests/test_isa.py checks that nothing else in the pi kernels reads or writes it), so it is not saved around them.
+// `on`: wave-uniform; a clear flag skips the statement (a branch INSIDE the asm: the unrolled sweep stays one basic block)
+__device__ __forceinline__ void t16_dma_row(unsigned on, const float *sbase, unsigned voff, unsigned lds_dst, float after)
+{
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n1:"
+                 : : "s"(on), "v"(voff), "s"(sbase), "s"(lds_dst), "v"(after) : "memory", "scc");
+}
+__device__ __forceinline__ void t16_dma_row2(unsigned on, const float *sbase, unsigned voff, unsigned lds_dst, float after0, float after1)
+{
+    // a 128-byte {lo, hi} row: pieces 2g and 2g + 1 into two consecutive 1 KB images (the instruction's immediate offset is added to the
+    // memory address AND to the LDS address: M0 advances by 1 KB - 16)
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_add_u32 m0, m0, 0x3f0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:16\n1:"
+                 : : "s"(on), "v"(voff), "s"(sbase), "s"(lds_dst), "v"(after0), "v"(after1) : "memory", "scc");
+}
+__device__ __forceinline__ void t16_wait_vm(int k) // k is a constant once the sweeps are unrolled
+{
+    if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (k == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (k == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (k == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (k == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (k == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (k == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (k == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // (a smaller count than the true one only waits longer)
+}
+// ring depths (step slots): what the 40 KB behind the slack of four waves hold — both tables through rings: 3 x 2 KB + 4 x 1 KB per wave; one of
+// them: 4 x 2 KB (beside a staged reference of <= 128 rows) / 6 x 1 KB (beside the staged bounds).  A row is fetched depth - 1 steps ahead.
+constexpr int t16_ring_b(bool XR) { return XR ? 3 : 4; }
+constexpr int t16_ring_x(bool BR) { return BR ? 4 : 6; }
+constexpr int T16_RING_B = 2048, T16_RING_X = 1024;           // bytes of a slot: {lo, hi} rows / reference rows of sixteen instances
+
 // COLD: the launch starts from reset_workspace() (RowParams::cold_start): no live-in array is read (round 3: a separate
 // instantiation — as a run-time branch the two initialisations meet in 270 phi values and the allocator spills)
 // MPC: the closed loop on chip (tiny_batch_mpc_run_async): P.mpc_steps solves of every tile inside the launch, the state staying in
 // registers / LDS between them — u_0, the plant step x0 <- Adyn x0 + Bdyn u_0 in the plant kernel's arithmetic, the window slide, the dual
 // reset and the terminal term happen on chip (quadrotor_tracking.cpp:93-118), like admm_rowlane.hip's MPC instantiation
-template <int N, bool EXACT, bool COLD, bool MPC = false>
+template <int N, bool EXACT, bool COLD, bool MPC = false, bool BR = false, bool XR = false>
 __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(const RowParams P)
 {
+    static_assert(!(MPC && (BR || XR)), "the closed loop on chip is instantiated for batch-shared bounds and a shared / windowed reference");
     constexpr int NX = 12, NU = 4;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
     const int ntiles = (P.batch + 15) >> 4;
@@ -381,20 +432,42 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
     extern __shared__ __attribute__((aligned(16))) float4 lds4_base[];
     float4 *const lds4 = lds4_base;
     float4 *const sn0 = lds4 + wv * (N * WAVE) + lane; // sn[i * WAVE]
-    float4 *const blo = lds4 + TILE16_WAVES * N * WAVE, *const bhi = blo + N * 4, *const tab0 = bhi + N * 4;
+    // behind the slack: the bounds — the shared table (2 x N float4 rows) or, BR, the four waves' slots (1 or DB x 2 KB each) —, then the
+    // reference — the shared table / trajectory table or, XR, the four waves' slots (1 or DX x 1 KB each)
+    constexpr int DB = t16_ring_b(XR), DX = t16_ring_x(BR);
+    const unsigned ringsB = (P.pi_flags & 1u) ? DB : 2, ringsX = (P.pi_flags & 2u) ? DX : 1; // resident bounds: the row of steps < N - 1 and the last step's
+    const unsigned bnd_f4 = BR ? TILE16_WAVES * ringsB * (T16_RING_B / 16) : 2 * N * 4;
+    float4 *const blo = lds4 + TILE16_WAVES * N * WAVE, *const bhi = blo + N * 4, *const tab0 = blo + bnd_f4;
     float4 *const tab = tab0;
     const int tab_rows = P.xref_mode == 1 ? P.table_rows : N;
     const float *tab_src = P.xref_mode == 1 ? P.xref_table : P.xref; // [rows][16]
-    for (int e = threadIdx.x; e < N * 16; e += WAVE * TILE16_WAVES)
+    unsigned dmaB = 0, dmaX = 0; // wave-uniform LDS address of the wave's slot 0 (DMA destination)
+    if constexpr (BR)
     {
-        const float2 lh = reinterpret_cast<const float2 *>(P.bounds)[e];
-        const int i = e >> 4, r = e & 15;
-        reinterpret_cast<float *>(&blo[i * 4 + (r & 3)])[r >> 2] = lh.x;
-        reinterpret_cast<float *>(&bhi[i * 4 + (r & 3)])[r >> 2] = lh.y;
+        const unsigned ring = (unsigned)(size_t)(lds_float4 *)blo + wv * (ringsB * T16_RING_B);
+        dmaB = __builtin_amdgcn_readfirstlane(ring);
     }
-    for (int e = threadIdx.x; e < tab_rows * 16; e += WAVE * TILE16_WAVES)
-        reinterpret_cast<float *>(&tab[(e >> 4) * 4 + (e & 3)])[(e & 15) >> 2] = tab_src[e];
-    __syncthreads();
+    else
+    {
+        for (int e = threadIdx.x; e < N * 16; e += WAVE * TILE16_WAVES)
+        {
+            const float2 lh = reinterpret_cast<const float2 *>(P.bounds)[e];
+            const int i = e >> 4, r = e & 15;
+            reinterpret_cast<float *>(&blo[i * 4 + (r & 3)])[r >> 2] = lh.x;
+            reinterpret_cast<float *>(&bhi[i * 4 + (r & 3)])[r >> 2] = lh.y;
+        }
+    }
+    if constexpr (XR)
+    {
+        const unsigned ring = (unsigned)(size_t)(lds_float4 *)tab0 + wv * (ringsX * T16_RING_X);
+        dmaX = __builtin_amdgcn_readfirstlane(ring);
+    }
+    else
+    {
+        for (int e = threadIdx.x; e < tab_rows * 16; e += WAVE * TILE16_WAVES)
+            reinterpret_cast<float *>(&tab[(e >> 4) * 4 + (e & 3)])[(e & 15) >> 2] = tab_src[e];
+    }
+    if constexpr (!BR || !XR) __syncthreads();
 
     TileMath<EXACT> M;
     M.load(P.mats, g, c);
@@ -488,13 +561,63 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
 #pragma unroll
     for (int v = 0; v < 3; v++) x0[v] = P.xu[ebase + 4 * v];
 
+    // BR / XR: byte offsets of the lane's DMA pieces from the arrays' bases (saddr + 32-bit offset addressing: the step's row offset is
+    // added to the uniform base, on the scalar unit)
+    const unsigned onB = BR ? (P.pi_flags & 1u) : 0u, onX = XR ? (P.pi_flags & 2u) : 0u; // the table changes along the horizon: ring of step slots
+    // The lane's addresses are made from its lane number where they are used: per tile (A0), and the reference's again per ITERATION (AI) from
+    // the slack address that is live there anyway (16 x lane = sn_addr - the wave's base).  Measured on the listing, scratch accesses per iteration
+    // of the warm-start exact instantiations (the register allocator sits at a cliff there; tests/test_isa.py pins the counts): reference
+    // addresses carried across the 5 000-instruction iteration body 199 -> made per iteration 34; the bounds' the other way round (42 carried,
+    // 281 remade), so those stay in two registers per tile there — and are remade per iteration in the cold-start instantiations (2 - 6 against
+    // 21 - 26; a scratch access is a full vector-memory round trip that a lone wave cannot hide: 20 of them per iteration measured 10 %)
+    struct PiAddr { unsigned rdB, rdX, voffB, voffX; };
+    auto pi_addr = [&](unsigned lane16) { // lane16 = 16 x lane
+        const unsigned c16 = lane16 & 0xf0u, gg = lane16 >> 8, cc = c16 >> 4;
+        const int ins = tile * 16 + (int)cc;
+        const unsigned ia = (unsigned)((tile_ok && ins < P.batch) ? ins : P.batch - 1);
+        PiAddr A;
+        A.rdB = dmaB + 1024u * (gg >> 1) + c16 + 8u * (gg & 1u); // pair {lo, hi} of row 4v + g: + 256 v
+        A.rdX = dmaX + c16 + 4u * gg;                            // element 4v + g: + 256 v
+        A.voffB = ia * P.bounds_inst_stride * 8u + 32u * gg;
+        A.voffX = ia * P.xref_inst_stride * 4u + 16u * gg;
+        return A;
+    };
+    // byte offset of the lane's piece of reference row i: W + 64 i, with W = the instance's array offset or — window of the trajectory table —
+    // 64 min(ws, rows - 1) + 16 g: the row kernels' table on the device carries N - 1 copies of its last row behind it (tiny_batch_set_xref_window),
+    // so the per-step clamp min(ws + i, rows - 1) needs no instruction here.  (As `mode == 1 ? … : …` per step hipcc emitted real branches, which cut
+    // the unrolled sweep into sixty scheduling regions: 6 - 8 %; a three-term branch-free form cost the warm-start instantiation a register: 207
+    // scratch accesses per iteration.)
+    auto xref_w = [&](unsigned voffXi, int ws) -> unsigned {
+        const int wc = ws < P.table_rows - 1 ? ws : P.table_rows - 1;
+        return P.xref_mode == 1 ? (unsigned)wc * 64u + 16u * g : voffXi;
+    };
+    const float *const xsrc = P.xref_mode == 1 ? P.xref_table : P.xref;
     // Xref_i for this lane: x rows in registers 0..2, register 3 = 0 (column 12 + g of the 16-wide table row)
     auto load_xref = [&](const float4 *tb, int ws, int i) {
+        if constexpr (XR) // prologue / epilogue (outside the sweeps): straight from memory
+        {
+            const float *rp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(xsrc) + (xref_w(pi_addr(16u * lane).voffX, ws) + (unsigned)i * 64u)) - 3 * g; // element g of the row
+            return f32x4{rp[0], rp[4], rp[8], 0.f};
+        }
+        else
+        {
         int row = ws + i;
         row = row < tab_rows ? row : tab_rows - 1;
         const float4 t4 = tb[row * 4 + g];
         return f32x4{t4.x, t4.y, t4.z, t4.w};
+        }
     };
+    PiAddr A0 = {0u, 0u, 0u, 0u};
+    if constexpr (BR || XR)
+    {
+        A0 = pi_addr(16u * lane);
+        // a table that does not change along the horizon: the tile's sixteen rows, once (the slot's previous readers — the last sweeps of the wave's
+        // previous tile — are long retired: its epilogue stored through the same LDS pipe since)
+        // (two rows of bounds: z has N - 1 columns — the input rows of the last step are not bounded, the table holds -inf | +inf there)
+        if constexpr (BR) { t16_dma_row2(onB ^ 1u, P.bounds, A0.voffB, dmaB, 0.f, 0.f); t16_dma_row2(onB ^ 1u, P.bounds, A0.voffB + (N - 1) * 128u, dmaB + T16_RING_B, 0.f, 0.f); }
+        if constexpr (XR) t16_dma_row((onX >> 1) ^ 1u, xsrc, A0.voffX, dmaX, 0.f);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     float pterm[3];
     {
         const f32x4 xrN4 = load_xref(tab, wstart, N - 1);
@@ -570,6 +693,48 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
         const int wsI = wstart + oz;
         const unsigned long long amask = __ballot(active); // instances still iterating: wave-uniform during the forward sweep
         const unsigned sn_addr = (unsigned)(size_t)(lds_float4 *)snI;
+        // BR / XR rings.  dma_x(i): reference row of step i -> slot i % 3; dma_b(i): {lo, hi} row of step i -> slot i % 3 (two pieces); both skip
+        // themselves when their table is one row per instance (fetched at the head of the tile).  `after` = a value that was read from the slot's
+        // previous occupant: the refill cannot be issued before that read has returned.
+        const float *const bsrcI = P.bounds + oz, *const xsrcI = xsrc + oz;
+        unsigned rdBI = 0, rdXI = 0, voffB = 0, voffXi = 0;
+        if constexpr (BR || XR)
+        {
+            const PiAddr AI = pi_addr(sn_addr - __builtin_amdgcn_readfirstlane(sn_addr)); // lane 0's slack address is the wave's base
+            rdBI = COLD ? AI.rdB : A0.rdB + oz; rdXI = AI.rdX; voffB = COLD ? AI.voffB : A0.voffB; voffXi = AI.voffX;
+        }
+        const unsigned sB1 = onB ? T16_RING_B : 0u, sX1 = onX ? T16_RING_X : 0u; // distance of the step slots (0: the one resident row)
+        const unsigned sBlast = onB ? ((N - 1) % DB) * T16_RING_B : T16_RING_B;
+        // (the step's row offset rides in the lane's 32-bit offset — one vector add per DMA —, not in the scalar base: thirty scalar base pairs per
+        //  sweep, hoisted to the head of the iteration by the scheduler, spilled scalar registers into vector lanes)
+        unsigned xw = 0;
+        if constexpr (XR) xw = xref_w(voffXi, wsI);
+        auto dma_x = [&](int i, float after) { t16_dma_row(onX, xsrcI, xw + (unsigned)i * 64u, dmaX + (i % DX) * T16_RING_X, after); };
+        auto dma_b = [&](int i, float after0, float after1) { t16_dma_row2(onB, bsrcI, voffB + (unsigned)i * 128u, dmaB + (i % DB) * T16_RING_B, after0, after1); };
+        typedef __attribute__((address_space(3))) const f32x2 lds_cfloat2;
+        typedef __attribute__((address_space(3))) const float lds_cfloat;
+        auto ring_bounds = [&](int i, float4 &lo, float4 &hi) { // the registers the shared tables deliver: rows 4v + g
+            // slot of step i: ring slot i % DB; resident rows: slot 0, and slot 1 for the last step
+            lds_cfloat2 *rp = reinterpret_cast<lds_cfloat2 *>(rdBI + (i == N - 1 ? sBlast : (i % DB) * sB1));
+            const f32x2 b0 = rp[0], b1 = rp[32], b2 = rp[64], b3 = rp[96];
+            lo = make_float4(b0.x, b1.x, b2.x, b3.x); hi = make_float4(b0.y, b1.y, b2.y, b3.y);
+        };
+        auto ring_xref = [&](int i) {
+            lds_cfloat *rp = reinterpret_cast<lds_cfloat *>(rdXI + (i % DX) * sX1);
+            return f32x4{rp[0], rp[64], rp[128], 0.f};
+        };
+        // the first DX reference rows of the backward sweep (every slot: the previous sweep consumed them), then the first DB - 1 steps' bounds:
+        // oldest first, so that every later counted wait has retired them
+        if constexpr (XR)
+        {
+#pragma unroll
+            for (int k = 0; k < DX; k++) dma_x(N - 2 - k, 0.f);
+        }
+        if constexpr (BR)
+        {
+#pragma unroll
+            for (int k = 0; k < DB - 1; k++) dma_b(k, 0.f, 0.f);
+        }
         // The arithmetic of a sweep runs for all 16 columns (the MFMAs are wave-wide); only the state updates of a
         // converged instance are masked, which freezes it exactly where the reference returns.
         // ---------------- forward sweep: forward_pass + update_slack + update_dual + residual maxima ----------------
@@ -607,7 +772,15 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
 #pragma unroll
         for (int i = 0; i < N; i++)
         {
-            const float4 lo = bloI[i * 4 + g], hi = bhiI[i * 4 + g], ol = snI[i * WAVE];
+            float4 lo, hi;
+            if constexpr (BR)
+            {
+                if (i + DB - 1 < N) dma_b(i + DB - 1, lo_p.x, hi_p.w); // into the slot of step i - 1, whose rows are in lo_p / hi_p
+                t16_wait_vm(2 * ((N - 1 - i) < (DB - 1) ? (N - 1 - i) : (DB - 1))); // the two pieces of step i have landed (newer: steps i + 1 .. i + DB - 1)
+                ring_bounds(i, lo, hi);
+            }
+            else { lo = bloI[i * 4 + g]; hi = bhiI[i * 4 + g]; }
+            const float4 ol = snI[i * WAVE];
             typename TileMath<EXACT>::InFlight F;
             if (i < N - 1) M.lqr_issue(s, F);
 #if TINY_T16_SCHED
@@ -646,19 +819,32 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
             // are in flight
             auto load_lin = [&](int i, float4 &sl, f32x4 &xr) { // LDS reads of step i's linear cost: issued a step ahead, in front of the MFMAs
                 sl = snI[i * WAVE];
-                xr = load_xref(tabI, wsI, i);
+                if constexpr (XR) xr = ring_xref(i);
+                else xr = load_xref(tabI, wsI, i);
             };
             auto make_lin = [&](int i, const float4 &sl, const f32x4 &xr) {
                 const f32x4 sni = {sl.x, sl.y, sl.z, sl.w};
                 return lin_cost4<EXACT>(-(xr * qv), rho4, sni - dual4(i)); // admm.cpp:80-82
             };
             float4 sl0; f32x4 xr0;
+            if constexpr (XR) t16_wait_vm(0); // rows N-2 .. N-1-DX were fetched at the head of the iteration
             load_lin(N - 2, sl0, xr0);
             f32x4 lin = make_lin(N - 2, sl0, xr0);
 #pragma unroll
             for (int i = N - 2; i >= 0; i--)
             {
                 float4 sl_n = make_float4(0.f, 0.f, 0.f, 0.f); f32x4 xr_n = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (XR)
+                {
+                    if (i >= DX) dma_x(i - DX, lin[0]); // into the slot of row i, which `lin` was made from
+                    // row i - 1 has landed; newer, still in flight: the rows j = i - 2 .. i - DX that this loop fetched (j <= N - 2 - DX; the DX rows above
+                    // that were fetched at the head of the iteration and are retired)
+                    if (i > 0)
+                    {
+                        const int hi_j = (i - 2) < (N - 2 - DX) ? (i - 2) : (N - 2 - DX), lo_j = (i - DX) > 0 ? (i - DX) : 0;
+                        t16_wait_vm(hi_j >= lo_j ? hi_j - lo_j + 1 : 0);
+                    }
+                }
                 if (EXACT && i > 0) load_lin(i - 1, sl_n, xr_n); // exact: in front of the MFMAs (measured 1.72 -> 1.69 ms; fma: 0.91 -> 0.93 the other way)
                 typename TileMath<EXACT>::InFlight F;
                 M.riccati_issue(p, lin, F);
@@ -842,8 +1028,58 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
 }
 
 // horizons: the slack of a wave is N KB of LDS, four waves and the shared tables must fit 160 KB: N <= 30
+#ifdef TINY_T16_ONLY30 // developer switch: one horizon, for quick looks at the listing
+#define TINY_FOR_EACH_TILE16(X) X(30)
+#else
 #define TINY_FOR_EACH_TILE16(X) X(30) X(25) X(20) X(10)
+#endif
 
+#ifdef TINY_T16_PI_UNIT
+// the PI instantiations are a translation unit of their own (admm_tile16_pi.hip includes this file): they compile beside the others, and the
+// device code of the shared-table instantiations — to which the recorded HBM traffic figures are bound (build.device_isa_sha) — does not move
+size_t tile16_pi_lds_bytes(int N, bool bounds_ring, bool xref_ring, unsigned pi_flags, int table_rows)
+{
+    const size_t bnd = bounds_ring ? (size_t)TILE16_WAVES * ((pi_flags & 1u) ? t16_ring_b(xref_ring) : 2) * T16_RING_B : (size_t)2 * N * 4 * sizeof(float4);
+    const size_t ref = xref_ring ? (size_t)TILE16_WAVES * ((pi_flags & 2u) ? t16_ring_x(bounds_ring) : 1) * T16_RING_X : (size_t)table_rows * 4 * sizeof(float4);
+    return (size_t)TILE16_WAVES * N * WAVE * sizeof(float4) + bnd + ref;
+}
+
+hipError_t launch_admm_tile16_pi(int N, bool exact, bool bounds_ring, bool xref_ring, const RowParams &P, hipStream_t stream, int n_cu)
+{
+    const int ntiles = (P.batch + 15) / 16;
+    if (n_cu <= 0) n_cu = 256;
+    const int want = (ntiles + TILE16_WAVES - 1) / TILE16_WAVES, nblocks = want < n_cu ? want : n_cu; // one persistent workgroup per CU
+    if (P.mpc_steps > 1 || (!bounds_ring && !xref_ring)) return hipErrorInvalidValue;
+    if (P.xref_mode == 1 && P.table_rows < 1) return hipErrorInvalidValue;
+    if (!bounds_ring && P.bounds_inst_stride != 0) return hipErrorInvalidValue;           // a staged table is the batch's
+    if (!xref_ring && P.xref_mode != 1 && P.xref_inst_stride != 0) return hipErrorInvalidValue;
+    if (xref_ring && P.xref_mode == 1 && !(P.pi_flags & 2u)) return hipErrorInvalidValue; // a window through the slots changes along the horizon
+    const size_t lds = tile16_pi_lds_bytes(N, bounds_ring, xref_ring, P.pi_flags, P.xref_mode == 1 ? P.table_rows : N);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+#define TINY_TILE16_PI_LAUNCH3(NN, EX, BRR, XRR)                                                                           \
+    {                                                                                                                      \
+        auto kern = P.cold_start ? admm_tile16_kernel<NN, EX, true, false, BRR, XRR> : admm_tile16_kernel<NN, EX, false, false, BRR, XRR>; \
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        if (e != hipSuccess) return e;                                                                                     \
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WAVE * TILE16_WAVES), lds, stream, P);                                \
+        return hipGetLastError();                                                                                          \
+    }
+#define TINY_TILE16_PI_LAUNCH(NN, EX)                                             \
+    {                                                                             \
+        if (bounds_ring && xref_ring) TINY_TILE16_PI_LAUNCH3(NN, EX, true, true)  \
+        else if (bounds_ring) TINY_TILE16_PI_LAUNCH3(NN, EX, true, false)         \
+        else TINY_TILE16_PI_LAUNCH3(NN, EX, false, true)                          \
+    }
+#define TINY_TILE16_PI_DISPATCH(NN)                  \
+    if (N == NN)                                     \
+    {                                                \
+        if (exact) TINY_TILE16_PI_LAUNCH(NN, true)   \
+        else TINY_TILE16_PI_LAUNCH(NN, false)        \
+    }
+    TINY_FOR_EACH_TILE16(TINY_TILE16_PI_DISPATCH)
+    return hipErrorInvalidValue;
+}
+#else
 bool tile16_supported(int nx, int nu, int N)
 {
     if (nx != 12 || nu != 4) return false;
@@ -881,5 +1117,6 @@ hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t
     TINY_FOR_EACH_TILE16(TINY_TILE16_DISPATCH)
     return hipErrorInvalidValue;
 }
+#endif // TINY_T16_PI_UNIT
 
 } // namespace tinympc

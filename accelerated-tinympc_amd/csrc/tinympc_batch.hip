@@ -275,6 +275,34 @@ __global__ void bounds_table_kernel(const float *__restrict__ xmin, const float 
     }
 }
 
+// Do the per-instance ROW tables change along the horizon?  vary[0]: the {lo, hi} table [nb][N][16] (x rows over all N steps, u rows over the
+// N - 1 steps that have an input), vary[1]: the reference [nb][N][16].  Bit patterns are compared.  admm_tile16_pi.hip keeps a table that does
+// not as ONE resident row per instance instead of streaming N of them through its ring every iteration (RowParams::pi_flags).
+__global__ void rows_vary_kernel(const float2 *__restrict__ bounds, const float *__restrict__ xref, int nb, int N, int nx, int nu, int *__restrict__ vary)
+{
+    const long long total = (long long)nb * 16;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x)
+    {
+        const int r = (int)(e & 15);
+        const long long b = e >> 4;
+        if (bounds && r < nx + nu)
+        {
+            const int steps = r < nx ? N : N - 1;
+            const unsigned long long *p = reinterpret_cast<const unsigned long long *>(bounds) + (b * N) * 16 + r;
+            bool differ = false;
+            for (int i = 1; i < steps; i++) differ |= p[(size_t)i * 16] != p[0];
+            if (differ) vary[0] = 1;
+        }
+        if (xref && r < nx)
+        {
+            const unsigned *p = reinterpret_cast<const unsigned *>(xref) + (b * N) * 16 + r;
+            bool differ = false;
+            for (int i = 1; i < N; i++) differ |= p[(size_t)i * 16] != p[0];
+            if (differ) vary[1] = 1;
+        }
+    }
+}
+
 int grid_for(long long total, int block = 256)
 {
     long long gsz = (total + block - 1) / block;
@@ -343,6 +371,8 @@ struct TinyBatch
     bool derived_dirty[2] = {true, true};
     float *t_xref = nullptr, *t_bnd[4] = {};              // TILE derived
     float *r_xref = nullptr, *r_bounds = nullptr;         // ROW derived
+    int *rows_vary_dev = nullptr;                         // [2] rows_vary_kernel's answer for the per-instance ROW tables ...
+    unsigned rows_vary = 3u;                              // ... bit 0: bounds, bit 1: reference (set = changes along the horizon)
     size_t r_xref_n = 0, r_bounds_n = 0, r_uref_n = 0;    // their allocated sizes in floats (sized_buffer)
     int graph_captures = 0;                               // closed-loop graphs captured so far (tiny_batch_debug_graph_captures)
     int n_cu = 256;                                       // compute units of the handle's device
@@ -805,6 +835,22 @@ int prepare_inputs(TinyBatch *tb, int layout)
             TRY(sized_buffer(&tb->r_uref, &tb->r_uref_n, tb->h16 ? (nu_f + 1) / 2 : nu_f));
             TRY(launch_pack(tb, tb->in_uref.dev, tb->r_uref, LAYOUT_ROW, 1, tb->in_uref.shared ? 1 : tb->batch, tb->in_uref.shared, 0, N - 1));
         }
+        // per-instance tables of the class the sixteen-instances-per-wave kernel serves: do they change along the horizon? (one pass, at set time)
+        tb->rows_vary = 3u;
+        const bool xper = tb->xref_mode != 1 && tb->in_xref.set && !tb->in_xref.shared;
+        if (tb->tile16_ok && !tb->h16 && tb->rw == 16 && (!bounds_all_shared(tb) || xper))
+        {
+            if (!tb->rows_vary_dev) TRY(dev_alloc_zero((float **)&tb->rows_vary_dev, 2));
+            HIP_TRY(hipMemsetAsync(tb->rows_vary_dev, 0, 2 * sizeof(int), tb->stream));
+            hipLaunchKernelGGL(rows_vary_kernel, dim3(grid_for((long long)tb->batch * 16)), dim3(256), 0, tb->stream,
+                               bounds_all_shared(tb) ? nullptr : reinterpret_cast<const float2 *>(tb->r_bounds), xper ? tb->r_xref : nullptr, tb->batch, N, nx, nu,
+                               tb->rows_vary_dev);
+            HIP_TRY(hipGetLastError());
+            int h[2] = {1, 1};
+            HIP_TRY(hipMemcpyAsync(h, tb->rows_vary_dev, sizeof h, hipMemcpyDeviceToHost, tb->stream));
+            HIP_TRY(hipStreamSynchronize(tb->stream));
+            tb->rows_vary = (h[0] ? 1u : 0u) | (h[1] ? 2u : 0u);
+        }
     }
     HIP_TRY(hipStreamSynchronize(tb->stream));
     tb->derived_dirty[layout] = false;
@@ -881,11 +927,45 @@ int resolve_variant(TinyBatch *tb, int *out)
 // HBM (rowstream).  tiny_batch_set_row_kernel() can force one of them.
 // admm_tile16.hip needs fp32 storage, a reference it does not have to keep resident (a window of a trajectory table that
 // fits its LDS share, or one shared reference) and — checked by the caller — batch-shared bounds and no optional terms
+// Round 4: per-instance bounds and a per-instance reference are served by the PI instantiations (rows fetched by LDS-DMA into per-wave rings,
+// admm_tile16_pi.hip), one solve per launch; a closed-loop run with either keeps the 16-lane kernel.
+bool tile16_per_instance(const TinyBatch *tb)
+{
+    static const bool force = getenv("TINYMPC_T16_FORCE_PI") != nullptr;
+    return force || !bounds_all_shared(tb) || (tb->xref_mode != 1 && tb->in_xref.set && !tb->in_xref.shared);
+}
+// which tables of a pi launch go through the per-wave LDS-DMA slots, and which of those change along the horizon (RowParams::pi_flags)
+struct Tile16Pi { bool bounds_ring, xref_ring; unsigned flags; };
+Tile16Pi tile16_pi_plan(const TinyBatch *tb)
+{
+    Tile16Pi p;
+    p.bounds_ring = !bounds_all_shared(tb);
+    p.xref_ring = tb->xref_mode != 1 && tb->in_xref.set && !tb->in_xref.shared;
+    static const char *force = getenv("TINYMPC_T16_FORCE_PI"); // experiment hook: shared tables through the slots ("b": bounds, "x": reference, else both)
+    if (force) { p.bounds_ring = force[0] != 'x'; p.xref_ring = force[0] != 'b'; }
+    p.flags = (p.bounds_ring ? (tb->rows_vary & 1u) : 0u) | (p.xref_ring ? (tb->rows_vary & 2u) : 0u);
+    if (force) p.flags = (p.bounds_ring ? 1u : 0u) | (p.xref_ring ? 2u : 0u);
+    const int rows = tb->xref_mode == 1 ? tb->table_rows : tb->N;
+    if (!p.xref_ring && tile16_pi_lds_bytes(tb->N, p.bounds_ring, false, p.flags, rows) > 160 * 1024)
+    {
+        p.xref_ring = true; p.flags |= 2u; // the staged table does not fit beside the bounds slots: the window goes through a ring as well
+    }
+    return p;
+}
+// automatic choice with per-instance tables (65 536 tracking instances, kernel ms, tile16 pi against the 16-lane kernel): tables that do not change along the
+// horizon 1.71 / 2.08 (bounds), through the rings with the longest-first dispatch 1.98 / 2.08 (bounds), 1.90 / 1.95 (reference), 2.04 / 2.15 (both); in index
+// order the rings lose (2.45 / 2.22): there the 16-lane kernel stays
+bool tile16_pi_auto(const TinyBatch *tb)
+{
+    if (tb->order_dev || tb->batch < kTile16AutoBatch) return false;
+    return tile16_pi_plan(tb).flags == 0u || tb->dispatch_mode == 1;
+}
 bool tile16_applies(const TinyBatch *tb)
 {
     if (!tb->tile16_ok || tb->h16) return false;
+    if (tile16_per_instance(tb)) return !tb->closed_loop_run; // any table length: a window is read through the ring too
     if (tb->xref_mode == 1) return tb->table_rows <= tile16_max_table_rows();
-    return !tb->in_xref.set || tb->in_xref.shared;
+    return true;
 }
 
 // auto between the two state-on-chip kernels of the nx = 32 class, by rounds of the launch (measured on the 256 CUs of an MI355X,
@@ -923,8 +1003,10 @@ int row_family(const TinyBatch *tb)
     if (!bounds_all_shared(tb))
     {
         if (tb->en_uref || tb->en_d2p) return 2;
-        if (tb->row_dims_ok && !tb->h16 && (tb->row_family_forced < 0 || tb->row_family_forced == 0)) return 0;
-        if (tb->rowloop_ok && (tb->row_family_forced < 0 || tb->row_family_forced == 1)) return 1; // one step ahead from global memory
+        if (tile16_applies(tb) && (tb->row_family_forced == 5 || (tb->row_family_forced < 0 && tile16_pi_auto(tb)))) return 5;
+        const int ff = tb->row_family_forced == 5 ? -1 : tb->row_family_forced; // tile16 asked for but not applicable (closed-loop run): like auto
+        if (tb->row_dims_ok && !tb->h16 && (ff < 0 || ff == 0)) return 0;
+        if (tb->rowloop_ok && (ff < 0 || ff == 1)) return 1; // one step ahead from global memory
         return 2;
     }
     if (tb->en_uref || tb->en_d2p) return 2; // the optional terms live in the streaming row kernel (c's u rows hold d elsewhere)
@@ -942,10 +1024,17 @@ int row_family(const TinyBatch *tb)
     // (round 4: tile16's MPC loop stays on chip too — tiny_batch_set_row_kernel(tb, 5) — but the warm-started solves of a closed loop are short and
     //  uneven, and sixteen instances in lock step lose more there than the matrix cores gain: measured 1.02 ms per MPC step of 65 536 tracking
     //  instances against 0.97 ms on the 16-lane kernel, so the automatic choice of a closed-loop run stays with the latter)
-    if (tile16_applies(tb) && !tb->closed_loop_run && !tb->order_dev && tb->batch >= kTile16AutoBatch) return 5;
+    if (tile16_applies(tb) && !tb->closed_loop_run && !tb->order_dev && tb->batch >= kTile16AutoBatch && (!tile16_per_instance(tb) || tile16_pi_auto(tb))) return 5;
     if (tb->row_dims_ok) return 0;
     if (tb->rowloop_ok) return 1;
     return 2;
+}
+
+hipError_t launch_tile16_pi(const TinyBatch *tb, bool exact, RowParams &P)
+{
+    const Tile16Pi pl = tile16_pi_plan(tb);
+    P.pi_flags = pl.flags;
+    return launch_admm_tile16_pi(tb->N, exact, pl.bounds_ring, pl.xref_ring, P, tb->stream, tb->n_cu);
 }
 
 void update_kname(TinyBatch *tb)
@@ -964,7 +1053,7 @@ void update_kname(TinyBatch *tb)
     else if (row_family(tb) == 6) snprintf(nm, sizeof nm, "waveres<%d,%d,%s>", tb->nx, tb->nu, ar);
     else if (row_family(tb) == 7) snprintf(nm, sizeof nm, "tile48<%d,%d,%d,%s>", tb->nx, tb->nu, tb->N, ar);
     else if (row_family(tb) == 4) snprintf(nm, sizeof nm, "quadlane<%d,%d,%d,%s%s>", tb->nx, tb->nu, tb->N, ar, sto);
-    else if (row_family(tb) == 5) snprintf(nm, sizeof nm, "tile16<%d,%d,%d,%s>", tb->nx, tb->nu, tb->N, ar);
+    else if (row_family(tb) == 5) snprintf(nm, sizeof nm, "tile16<%d,%d,%d,%s%s>", tb->nx, tb->nu, tb->N, ar, tile16_per_instance(tb) ? ",pi" : "");
     else snprintf(nm, sizeof nm, "rowstream<%d,%d,%s%s>", tb->nx, tb->nu, ar, sto);
     tb->kname = nm;
 }
@@ -980,6 +1069,7 @@ void fill_row_params(TinyBatch *tb, RowParams &P, bool exact)
     P.xu = tb->pair[0]; P.qr = tb->pair[1]; P.pd = tb->pair[2]; P.vz = tb->pair[3]; P.vzn = tb->pair[4]; P.gy = tb->pair[5];
     P.xref = tb->r_xref;
     P.xref_inst_stride = (tb->in_xref.set && !tb->in_xref.shared) ? (unsigned)(tb->N * tb->rw) : 0u;
+    P.pi_flags = 0u;
     P.xref_table = tb->h16 ? tb->tab_row_h : tb->tab_row; P.xref_start = tb->xref_start; P.table_rows = tb->table_rows;
     P.bounds = tb->r_bounds;
     P.bounds_inst_stride = bounds_all_shared(tb) ? 0u : (unsigned)(tb->N * tb->rw);
@@ -1135,7 +1225,8 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
             : fam == 1 ? launch_admm_rowloop(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
             : fam == 3 ? launch_admm_wavestream(tb->nx, tb->nu, P, tb->stream)
             : fam == 4 ? launch_admm_quadlane(tb->N, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
-            : fam == 5 ? launch_admm_tile16(tb->N, v == VAR_ROW_EXACT, P, tb->stream, tb->n_cu)
+            : fam == 5 ? (tile16_per_instance(tb) ? launch_tile16_pi(tb, v == VAR_ROW_EXACT, P)
+                                                  : launch_admm_tile16(tb->N, v == VAR_ROW_EXACT, P, tb->stream, tb->n_cu))
             : fam == 6 ? launch_admm_waveres(tb->nx, tb->nu, v == VAR_ROW_EXACT, P, tb->stream)
             : fam == 7 ? launch_admm_tile48(tb->N, v == VAR_ROW_EXACT, P, tb->stream)
                        : launch_admm_rowstream(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream);
@@ -1266,7 +1357,7 @@ void tiny_batch_destroy(TinyBatch *tb)
     (void)guarded_free(tb->in_uref.dev); (void)guarded_free(tb->r_uref);
     (void)guarded_free(tb->key_buf); (void)guarded_free(tb->order_buf); (void)guarded_free(tb->u0_stage);
     for (int k = 0; k < 4; k++) { (void)guarded_free(tb->in_bnd[k].dev); (void)guarded_free(tb->t_bnd[k]); }
-    (void)guarded_free(tb->t_xref); (void)guarded_free(tb->r_xref); (void)guarded_free(tb->r_bounds);
+    (void)guarded_free(tb->t_xref); (void)guarded_free(tb->r_xref); (void)guarded_free(tb->r_bounds); (void)guarded_free((float *)tb->rows_vary_dev);
     (void)guarded_free(tb->tab_tile); (void)guarded_free(tb->tab_row); (void)guarded_free(tb->tab_row_h); (void)guarded_free(tb->xref_start);
     (void)guarded_free(tb->res); (void)guarded_free(tb->status); (void)guarded_free(tb->iter); (void)guarded_free(tb->n_unsolved);
     (void)guarded_free(tb->opnd); (void)guarded_free(tb->qvec); (void)guarded_free(tb->gen_mats); (void)guarded_free(tb->mats_exact); (void)guarded_free(tb->mats_fast);
@@ -1434,12 +1525,14 @@ int tiny_batch_set_xref_window(TinyBatch *tb, const float *table, int rows, cons
             return fail(TINY_BATCH_EINVAL, "window start[%d]=%d out of range for %d rows, N=%d", b, start[b], rows, tb->N);
     TRY(set_device(tb));
     // table on the device in both forms: [rows][4 gq][NXC] (streaming kernel) and [rows][rw] (row / wave kernels)
-    std::vector<float> tt((size_t)rows * 4 * tb->NXC, 0.f), tr((size_t)rows * tb->rw, 0.f);
-    for (int r = 0; r < rows; r++)
+    // (the row form carries N - 1 copies of its last row behind it: a window that has slid past the end reads them instead of clamping every
+    //  step's row index — admm_tile16_pi.hip; the other kernels clamp and never look there)
+    std::vector<float> tt((size_t)rows * 4 * tb->NXC, 0.f), tr((size_t)(rows + tb->N - 1) * tb->rw, 0.f);
+    for (int r = 0; r < rows + tb->N - 1; r++)
         for (int row = 0; row < tb->nx; row++)
         {
-            const float v = table[(size_t)r * tb->nx + row];
-            tt[((size_t)r * 4 + (row & 3)) * tb->NXC + (row >> 2)] = v;
+            const float v = table[(size_t)(r < rows ? r : rows - 1) * tb->nx + row];
+            if (r < rows) tt[((size_t)r * 4 + (row & 3)) * tb->NXC + (row >> 2)] = v;
             if (row < tb->rw) tr[(size_t)r * tb->rw + row] = v;
         }
     if (tb->table_rows != rows)
@@ -1873,6 +1966,15 @@ int tiny_batch_last_solve_ms(TinyBatch *tb, float *ms)
 const char *tiny_batch_kernel_name(TinyBatch *tb)
 {
     if (!tb) return "";
+    // per-instance tables of the class admm_tile16_pi.hip serves: whether they change along the horizon (one resident row per instance, or rings)
+    // is found when the derived tables are built, and the automatic choice depends on it — build them now, as the next solve would
+    if (tb->tile16_ok && !tb->h16 && tb->derived_dirty[LAYOUT_ROW] && tile16_per_instance(tb))
+    {
+        const std::string keep = g_err;
+        int v = 0;
+        (void)prepare_solve(tb, &v); // (not ready yet: the name is then the one the present knowledge gives)
+        g_err = keep;
+    }
     update_kname(tb);
     return tb->kname.c_str();
 }
