@@ -376,6 +376,11 @@ constexpr int TILE16_MAX_TABLE_ROWS = 512;
 //   * a table that does (bit set) goes through a ring of three step slots, two steps ahead of its use, retired with counted `s_waitcnt vmcnt`;
 //     a slot is refilled only after the values read from it have been consumed (the DMA statement takes one of them as an operand).  A
 //     DMA costs a lone wave about 30 clocks of issue (M0, one wait state, the instruction): three per step pair are 8 % of it.
+//   * ring tables come from TILE IMAGES (tile16_image_kernel, built when the inputs are set): [tile][step][piece][lane][16 B], i.e. exactly the LDS
+//     image of a slot, so that a DMA reads 1 KB of consecutive bytes in whole 128-byte lines — from the [instance][step][16] arrays the same DMA is
+//     sixteen half lines 1 920 B apart, and a CU's outstanding misses, not the memory, bound the ring (measured: reference ring 1.93 -> … ms).
+//     RowParams::bounds / ::xref point to the images then.  (A window of the trajectory table is never read through a ring: with a table too
+//     long for the LDS share beside the bounds' slots the handle keeps the 16-lane kernel.)
 // The other table of a BR-only / XR-only instantiation is the batch-shared one staged in LDS, as in the base kernel.  hipcc does not count an
 // asm DMA in its own s_waitcnt bookkeeping; the iteration loop issues no other vector memory instruction, and a foreign entry in the
 // in-order counter can only make either side's counted wait longer, never shorter.  M0 is written by these statements only
@@ -392,6 +397,13 @@ __device__ __forceinline__ void t16_dma_row2(unsigned on, const float *sbase, un
     // memory address AND to the LDS address: M0 advances by 1 KB - 16)
     asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
                  "s_add_u32 m0, m0, 0x3f0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:16\n1:"
+                 : : "s"(on), "v"(voff), "s"(sbase), "s"(lds_dst), "v"(after0), "v"(after1) : "memory", "scc");
+}
+// the same row from its tile image (below): the two 1 KB pieces are 1 KB apart in memory AND in LDS — the immediate offset moves both, M0 stays
+__device__ __forceinline__ void t16_dma_img2(unsigned on, const float *sbase, unsigned voff, unsigned lds_dst, float after0, float after1)
+{
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024\n1:"
                  : : "s"(on), "v"(voff), "s"(sbase), "s"(lds_dst), "v"(after0), "v"(after1) : "memory", "scc");
 }
 __device__ __forceinline__ void t16_wait_vm(int k) // k is a constant once the sweeps are unrolled
@@ -564,12 +576,11 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
     // BR / XR: byte offsets of the lane's DMA pieces from the arrays' bases (saddr + 32-bit offset addressing: the step's row offset is
     // added to the uniform base, on the scalar unit)
     const unsigned onB = BR ? (P.pi_flags & 1u) : 0u, onX = XR ? (P.pi_flags & 2u) : 0u; // the table changes along the horizon: ring of step slots
-    // The lane's addresses are made from its lane number where they are used: per tile (A0), and the reference's again per ITERATION (AI) from
-    // the slack address that is live there anyway (16 x lane = sn_addr - the wave's base).  Measured on the listing, scratch accesses per iteration
-    // of the warm-start exact instantiations (the register allocator sits at a cliff there; tests/test_isa.py pins the counts): reference
-    // addresses carried across the 5 000-instruction iteration body 199 -> made per iteration 34; the bounds' the other way round (42 carried,
-    // 281 remade), so those stay in two registers per tile there — and are remade per iteration in the cold-start instantiations (2 - 6 against
-    // 21 - 26; a scratch access is a full vector-memory round trip that a lone wave cannot hide: 20 of them per iteration measured 10 %)
+    // The lane's addresses are made from its lane number: per tile (A0: carried across the iteration loop) in the warm-start instantiations, per
+    // ITERATION (AI: from the slack address that is live there anyway, 16 x lane = sn_addr - the wave's base) in the cold-start ones.  The register
+    // allocator sits at a cliff in this kernel and the two kinds tip opposite ways (scratch accesses per iteration on the listing, pinned by
+    // tests/test_isa.py): cold start 2 - 5 remade against 21 - 26 carried, warm start 33 - 36 carried against 170 - 300 remade.  A scratch access is
+    // a vector-memory round trip that a lone wave cannot hide: twenty of them per iteration measured 10 %.
     struct PiAddr { unsigned rdB, rdX, voffB, voffX; };
     auto pi_addr = [&](unsigned lane16) { // lane16 = 16 x lane
         const unsigned c16 = lane16 & 0xf0u, gg = lane16 >> 8, cc = c16 >> 4;
@@ -582,21 +593,24 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
         A.voffX = ia * P.xref_inst_stride * 4u + 16u * gg;
         return A;
     };
-    // byte offset of the lane's piece of reference row i: W + 64 i, with W = the instance's array offset or — window of the trajectory table —
-    // 64 min(ws, rows - 1) + 16 g: the row kernels' table on the device carries N - 1 copies of its last row behind it (tiny_batch_set_xref_window),
-    // so the per-step clamp min(ws + i, rows - 1) needs no instruction here.  (As `mode == 1 ? … : …` per step hipcc emitted real branches, which cut
-    // the unrolled sweep into sixty scheduling regions: 6 - 8 %; a three-term branch-free form cost the warm-start instantiation a register: 207
-    // scratch accesses per iteration.)
-    auto xref_w = [&](unsigned voffXi, int ws) -> unsigned {
-        const int wc = ws < P.table_rows - 1 ? ws : P.table_rows - 1;
-        return P.xref_mode == 1 ? (unsigned)wc * 64u + 16u * g : voffXi;
-    };
-    const float *const xsrc = P.xref_mode == 1 ? P.xref_table : P.xref;
+    const float *const xsrc = P.xref; // XR: the per-instance array (one resident row per instance) or its tile image (ring): row i of the tile at
+                                      // ((tile N + i) 64 + lane) 16 bytes
     // Xref_i for this lane: x rows in registers 0..2, register 3 = 0 (column 12 + g of the 16-wide table row)
     auto load_xref = [&](const float4 *tb, int ws, int i) {
         if constexpr (XR) // prologue / epilogue (outside the sweeps): straight from memory
         {
-            const float *rp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(xsrc) + (xref_w(pi_addr(16u * lane).voffX, ws) + (unsigned)i * 64u)) - 3 * g; // element g of the row
+            // (the lane number passes through an opaque statement: the addresses below are then made where they are used — hoisted in front of the
+            //  iteration loop and carried across it they push the warm-start instantiations over the allocator's cliff)
+            unsigned ll = lane;
+            asm volatile("" : "+v"(ll));
+            const unsigned cc = ll & 15u, gg = ll >> 4;
+            if (onX) // element 4v + g of instance c: piece v = lane 16 v + c of the image row, word g
+            {
+                const float *rp = xsrc + ((size_t)((tile_ok ? tile : 0) * N + i) * 64 + cc) * 4 + gg;
+                return f32x4{rp[0], rp[64], rp[128], 0.f};
+            }
+            const int ins = tile * 16 + (int)cc;
+            const float *rp = xsrc + (size_t)((tile_ok && ins < P.batch) ? ins : P.batch - 1) * P.xref_inst_stride + i * 16 + gg; // element g of the row
             return f32x4{rp[0], rp[4], rp[8], 0.f};
         }
         else
@@ -615,7 +629,7 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
         // previous tile — are long retired: its epilogue stored through the same LDS pipe since)
         // (two rows of bounds: z has N - 1 columns — the input rows of the last step are not bounded, the table holds -inf | +inf there)
         if constexpr (BR) { t16_dma_row2(onB ^ 1u, P.bounds, A0.voffB, dmaB, 0.f, 0.f); t16_dma_row2(onB ^ 1u, P.bounds, A0.voffB + (N - 1) * 128u, dmaB + T16_RING_B, 0.f, 0.f); }
-        if constexpr (XR) t16_dma_row((onX >> 1) ^ 1u, xsrc, A0.voffX, dmaX, 0.f);
+        if constexpr (XR) t16_dma_row((onX >> 1) ^ 1u, xsrc, A0.voffX, dmaX, 0.f); // (a resident reference row is never an image)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     float pterm[3];
@@ -697,20 +711,24 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
         // themselves when their table is one row per instance (fetched at the head of the tile).  `after` = a value that was read from the slot's
         // previous occupant: the refill cannot be issued before that read has returned.
         const float *const bsrcI = P.bounds + oz, *const xsrcI = xsrc + oz;
-        unsigned rdBI = 0, rdXI = 0, voffB = 0, voffXi = 0;
+        unsigned rdBI = 0, rdXI = 0;
         if constexpr (BR || XR)
         {
             const PiAddr AI = pi_addr(sn_addr - __builtin_amdgcn_readfirstlane(sn_addr)); // lane 0's slack address is the wave's base
-            rdBI = COLD ? AI.rdB : A0.rdB + oz; rdXI = AI.rdX; voffB = COLD ? AI.voffB : A0.voffB; voffXi = AI.voffX;
+            rdBI = COLD ? AI.rdB : A0.rdB + oz; rdXI = COLD ? AI.rdX : A0.rdX + oz;
         }
         const unsigned sB1 = onB ? T16_RING_B : 0u, sX1 = onX ? T16_RING_X : 0u; // distance of the step slots (0: the one resident row)
         const unsigned sBlast = onB ? ((N - 1) % DB) * T16_RING_B : T16_RING_B;
         // (the step's row offset rides in the lane's 32-bit offset — one vector add per DMA —, not in the scalar base: thirty scalar base pairs per
         //  sweep, hoisted to the head of the iteration by the scheduler, spilled scalar registers into vector lanes)
-        unsigned xw = 0;
-        if constexpr (XR) xw = xref_w(voffXi, wsI);
-        auto dma_x = [&](int i, float after) { t16_dma_row(onX, xsrcI, xw + (unsigned)i * 64u, dmaX + (i % DX) * T16_RING_X, after); };
-        auto dma_b = [&](int i, float after0, float after1) { t16_dma_row2(onB, bsrcI, voffB + (unsigned)i * 128u, dmaB + (i % DB) * T16_RING_B, after0, after1); };
+        // ring sources: the bounds' tile image (2 KB per step), the reference's tile image (1 KB per step)
+        const unsigned lane16I = sn_addr - __builtin_amdgcn_readfirstlane(sn_addr);
+        const unsigned timg = (unsigned)(tile_ok ? tile : 0) * (unsigned)N; // image row of step 0
+        unsigned xw = 0, bw = 0;
+        if constexpr (XR) xw = timg * 1024u + (COLD ? lane16I : 16u * lane);
+        if constexpr (BR) bw = timg * 2048u + (COLD ? lane16I : 16u * lane);
+        auto dma_x = [&](int i, float after) { t16_dma_row(onX, xsrcI, xw + (unsigned)i * 1024u, dmaX + (i % DX) * T16_RING_X, after); };
+        auto dma_b = [&](int i, float after0, float after1) { t16_dma_img2(onB, bsrcI, bw + (unsigned)i * 2048u, dmaB + (i % DB) * T16_RING_B, after0, after1); };
         typedef __attribute__((address_space(3))) const f32x2 lds_cfloat2;
         typedef __attribute__((address_space(3))) const float lds_cfloat;
         auto ring_bounds = [&](int i, float4 &lo, float4 &hi) { // the registers the shared tables deliver: rows 4v + g
@@ -1053,7 +1071,7 @@ hipError_t launch_admm_tile16_pi(int N, bool exact, bool bounds_ring, bool xref_
     if (P.xref_mode == 1 && P.table_rows < 1) return hipErrorInvalidValue;
     if (!bounds_ring && P.bounds_inst_stride != 0) return hipErrorInvalidValue;           // a staged table is the batch's
     if (!xref_ring && P.xref_mode != 1 && P.xref_inst_stride != 0) return hipErrorInvalidValue;
-    if (xref_ring && P.xref_mode == 1 && !(P.pi_flags & 2u)) return hipErrorInvalidValue; // a window through the slots changes along the horizon
+    if (xref_ring && P.xref_mode == 1) return hipErrorInvalidValue; // a window of the trajectory table is staged, never read through the slots
     const size_t lds = tile16_pi_lds_bytes(N, bounds_ring, xref_ring, P.pi_flags, P.xref_mode == 1 ? P.table_rows : N);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
 #define TINY_TILE16_PI_LAUNCH3(NN, EX, BRR, XRR)                                                                           \

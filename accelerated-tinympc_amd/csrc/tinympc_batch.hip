@@ -275,6 +275,23 @@ __global__ void bounds_table_kernel(const float *__restrict__ xmin, const float 
     }
 }
 
+// Tile images of the ROW tables for the LDS-DMA rings of admm_tile16_pi.hip: dst[tile][step][piece][lane = 16 g + c] (float4) = words 4 (P g + piece) .. + 3 of
+// row `step` of instance 16 tile + c, P = pieces per lane (1: the 16-float reference rows, 2: the 32-float {lo, hi} rows) — byte for byte what a ring slot
+// holds, so that one DMA reads 1 KB of consecutive memory.  Columns past the batch repeat its last instance (they are computed and never stored).
+__global__ void tile16_image_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, int nb, int N, int pieces, long long inst_stride_f4)
+{
+    const long long total = (long long)((nb + 15) / 16) * N * pieces * 64;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x)
+    {
+        const int lane = (int)(e & 63), piece = (int)((e >> 6) % pieces);
+        const long long t = e / (64 * pieces);
+        const int step = (int)(t % N), g = lane >> 4, c = lane & 15;
+        long long inst = (t / N) * 16 + c;
+        inst = inst < nb ? inst : nb - 1;
+        dst[e] = src[inst * inst_stride_f4 + (long long)step * 4 * pieces + pieces * g + piece];
+    }
+}
+
 // Do the per-instance ROW tables change along the horizon?  vary[0]: the {lo, hi} table [nb][N][16] (x rows over all N steps, u rows over the
 // N - 1 steps that have an input), vary[1]: the reference [nb][N][16].  Bit patterns are compared.  admm_tile16_pi.hip keeps a table that does
 // not as ONE resident row per instance instead of streaming N of them through its ring every iteration (RowParams::pi_flags).
@@ -371,6 +388,8 @@ struct TinyBatch
     bool derived_dirty[2] = {true, true};
     float *t_xref = nullptr, *t_bnd[4] = {};              // TILE derived
     float *r_xref = nullptr, *r_bounds = nullptr;         // ROW derived
+    float *r_bounds_img = nullptr, *r_xref_img = nullptr; // tile images of the two tables when they go through the rings of admm_tile16_pi.hip
+    size_t r_bounds_img_n = 0, r_xref_img_n = 0;
     int *rows_vary_dev = nullptr;                         // [2] rows_vary_kernel's answer for the per-instance ROW tables ...
     unsigned rows_vary = 3u;                              // ... bit 0: bounds, bit 1: reference (set = changes along the horizon)
     size_t r_xref_n = 0, r_bounds_n = 0, r_uref_n = 0;    // their allocated sizes in floats (sized_buffer)
@@ -850,6 +869,21 @@ int prepare_inputs(TinyBatch *tb, int layout)
             HIP_TRY(hipMemcpyAsync(h, tb->rows_vary_dev, sizeof h, hipMemcpyDeviceToHost, tb->stream));
             HIP_TRY(hipStreamSynchronize(tb->stream));
             tb->rows_vary = (h[0] ? 1u : 0u) | (h[1] ? 2u : 0u);
+            const long long ntl = (tb->batch + 15) / 16;
+            if (!bounds_all_shared(tb) && (tb->rows_vary & 1u))
+            {
+                TRY(sized_buffer(&tb->r_bounds_img, &tb->r_bounds_img_n, (size_t)ntl * N * 2 * 64 * 4));
+                hipLaunchKernelGGL(tile16_image_kernel, dim3(grid_for(ntl * N * 128)), dim3(256), 0, tb->stream, reinterpret_cast<const float4 *>(tb->r_bounds),
+                                   reinterpret_cast<float4 *>(tb->r_bounds_img), tb->batch, N, 2, (long long)N * 8);
+                HIP_TRY(hipGetLastError());
+            }
+            if (xper && (tb->rows_vary & 2u))
+            {
+                TRY(sized_buffer(&tb->r_xref_img, &tb->r_xref_img_n, (size_t)ntl * N * 64 * 4));
+                hipLaunchKernelGGL(tile16_image_kernel, dim3(grid_for(ntl * N * 64)), dim3(256), 0, tb->stream, reinterpret_cast<const float4 *>(tb->r_xref),
+                                   reinterpret_cast<float4 *>(tb->r_xref_img), tb->batch, N, 1, (long long)N * 4);
+                HIP_TRY(hipGetLastError());
+            }
         }
     }
     HIP_TRY(hipStreamSynchronize(tb->stream));
@@ -931,25 +965,18 @@ int resolve_variant(TinyBatch *tb, int *out)
 // admm_tile16_pi.hip), one solve per launch; a closed-loop run with either keeps the 16-lane kernel.
 bool tile16_per_instance(const TinyBatch *tb)
 {
-    static const bool force = getenv("TINYMPC_T16_FORCE_PI") != nullptr;
-    return force || !bounds_all_shared(tb) || (tb->xref_mode != 1 && tb->in_xref.set && !tb->in_xref.shared);
+    return !bounds_all_shared(tb) || (tb->xref_mode != 1 && tb->in_xref.set && !tb->in_xref.shared);
 }
 // which tables of a pi launch go through the per-wave LDS-DMA slots, and which of those change along the horizon (RowParams::pi_flags)
-struct Tile16Pi { bool bounds_ring, xref_ring; unsigned flags; };
+struct Tile16Pi { bool bounds_ring, xref_ring, fits; unsigned flags; }; // flags: RowParams::pi_flags
 Tile16Pi tile16_pi_plan(const TinyBatch *tb)
 {
     Tile16Pi p;
     p.bounds_ring = !bounds_all_shared(tb);
     p.xref_ring = tb->xref_mode != 1 && tb->in_xref.set && !tb->in_xref.shared;
-    static const char *force = getenv("TINYMPC_T16_FORCE_PI"); // experiment hook: shared tables through the slots ("b": bounds, "x": reference, else both)
-    if (force) { p.bounds_ring = force[0] != 'x'; p.xref_ring = force[0] != 'b'; }
     p.flags = (p.bounds_ring ? (tb->rows_vary & 1u) : 0u) | (p.xref_ring ? (tb->rows_vary & 2u) : 0u);
-    if (force) p.flags = (p.bounds_ring ? 1u : 0u) | (p.xref_ring ? 2u : 0u);
     const int rows = tb->xref_mode == 1 ? tb->table_rows : tb->N;
-    if (!p.xref_ring && tile16_pi_lds_bytes(tb->N, p.bounds_ring, false, p.flags, rows) > 160 * 1024)
-    {
-        p.xref_ring = true; p.flags |= 2u; // the staged table does not fit beside the bounds slots: the window goes through a ring as well
-    }
+    p.fits = tile16_pi_lds_bytes(tb->N, p.bounds_ring, p.xref_ring, p.flags, rows) <= 160 * 1024; // a staged table too long for the LDS share beside the slots
     return p;
 }
 // automatic choice with per-instance tables (65 536 tracking instances, kernel ms, tile16 pi against the 16-lane kernel): tables that do not change along the
@@ -963,7 +990,7 @@ bool tile16_pi_auto(const TinyBatch *tb)
 bool tile16_applies(const TinyBatch *tb)
 {
     if (!tb->tile16_ok || tb->h16) return false;
-    if (tile16_per_instance(tb)) return !tb->closed_loop_run; // any table length: a window is read through the ring too
+    if (tile16_per_instance(tb)) return !tb->closed_loop_run && tile16_pi_plan(tb).fits;
     if (tb->xref_mode == 1) return tb->table_rows <= tile16_max_table_rows();
     return true;
 }
@@ -1034,6 +1061,17 @@ hipError_t launch_tile16_pi(const TinyBatch *tb, bool exact, RowParams &P)
 {
     const Tile16Pi pl = tile16_pi_plan(tb);
     P.pi_flags = pl.flags;
+    // ring tables are read from their tile images (a window of the trajectory table through the ring: from the table's rows)
+    if (pl.bounds_ring && (pl.flags & 1u))
+    {
+        if (!tb->r_bounds_img) return hipErrorInvalidValue;
+        P.bounds = tb->r_bounds_img;
+    }
+    if (pl.xref_ring && (pl.flags & 2u))
+    {
+        if (!tb->r_xref_img) return hipErrorInvalidValue;
+        P.xref = tb->r_xref_img;
+    }
     return launch_admm_tile16_pi(tb->N, exact, pl.bounds_ring, pl.xref_ring, P, tb->stream, tb->n_cu);
 }
 
@@ -1358,6 +1396,7 @@ void tiny_batch_destroy(TinyBatch *tb)
     (void)guarded_free(tb->key_buf); (void)guarded_free(tb->order_buf); (void)guarded_free(tb->u0_stage);
     for (int k = 0; k < 4; k++) { (void)guarded_free(tb->in_bnd[k].dev); (void)guarded_free(tb->t_bnd[k]); }
     (void)guarded_free(tb->t_xref); (void)guarded_free(tb->r_xref); (void)guarded_free(tb->r_bounds); (void)guarded_free((float *)tb->rows_vary_dev);
+    (void)guarded_free(tb->r_bounds_img); (void)guarded_free(tb->r_xref_img);
     (void)guarded_free(tb->tab_tile); (void)guarded_free(tb->tab_row); (void)guarded_free(tb->tab_row_h); (void)guarded_free(tb->xref_start);
     (void)guarded_free(tb->res); (void)guarded_free(tb->status); (void)guarded_free(tb->iter); (void)guarded_free(tb->n_unsolved);
     (void)guarded_free(tb->opnd); (void)guarded_free(tb->qvec); (void)guarded_free(tb->gen_mats); (void)guarded_free(tb->mats_exact); (void)guarded_free(tb->mats_fast);
@@ -1525,14 +1564,12 @@ int tiny_batch_set_xref_window(TinyBatch *tb, const float *table, int rows, cons
             return fail(TINY_BATCH_EINVAL, "window start[%d]=%d out of range for %d rows, N=%d", b, start[b], rows, tb->N);
     TRY(set_device(tb));
     // table on the device in both forms: [rows][4 gq][NXC] (streaming kernel) and [rows][rw] (row / wave kernels)
-    // (the row form carries N - 1 copies of its last row behind it: a window that has slid past the end reads them instead of clamping every
-    //  step's row index — admm_tile16_pi.hip; the other kernels clamp and never look there)
-    std::vector<float> tt((size_t)rows * 4 * tb->NXC, 0.f), tr((size_t)(rows + tb->N - 1) * tb->rw, 0.f);
-    for (int r = 0; r < rows + tb->N - 1; r++)
+    std::vector<float> tt((size_t)rows * 4 * tb->NXC, 0.f), tr((size_t)rows * tb->rw, 0.f);
+    for (int r = 0; r < rows; r++)
         for (int row = 0; row < tb->nx; row++)
         {
-            const float v = table[(size_t)(r < rows ? r : rows - 1) * tb->nx + row];
-            if (r < rows) tt[((size_t)r * 4 + (row & 3)) * tb->NXC + (row >> 2)] = v;
+            const float v = table[(size_t)r * tb->nx + row];
+            tt[((size_t)r * 4 + (row & 3)) * tb->NXC + (row >> 2)] = v;
             if (row < tb->rw) tr[(size_t)r * tb->rw + row] = v;
         }
     if (tb->table_rows != rows)

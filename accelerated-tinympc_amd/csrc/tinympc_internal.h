@@ -89,8 +89,8 @@ struct RowParams
     const float *xref;           // [batch or 1][N][16]
     unsigned xref_inst_stride;   // floats between instances (0 = shared)
     unsigned pi_flags;           // admm_tile16_pi.hip only (fills a padding hole: no other kernel's argument layout moves).  bit 0: the {lo, hi} rows differ
-                                 // from step to step (ring of three step slots; clear = one row per instance, fetched once per tile), bit 1: the same for the
-                                 // reference rows
+                                 // from step to step (`bounds` is then their tile image, read through a ring of step slots; clear = one row per instance, fetched
+                                 // once per tile from the [B][N][16] table), bit 1: the same for the reference rows and `xref`
     const float *xref_table;     // [rows][16]
     int *xref_start;             // [batch] window start; advanced by the closed-loop kernels
     int table_rows;

@@ -229,8 +229,11 @@ extern "C"
      * 2 = rowloop (rolled loops, state in registers/LDS, any N <= 64), 3 = rowstream (any N, state in HBM),
      * 4 = quadlane (4 lanes per instance, nx = 4 and nu = 1 only), 5 = tile16 (16 instances per wavefront as the columns of
      * a 16x16 MFMA tile, gain x state products on the matrix cores in both arithmetic modes, state in registers/LDS; nx = 12,
-     * nu = 4 and an instantiated horizon; on request only; with a per-instance reference array or fp16 storage the handle
-     * falls back to the auto choice).  For 16 < nx + nu <= 64 (one wavefront per instance): 6 = wavestream (state in HBM, any
+     * nu = 4 and an instantiated horizon; the auto choice from 32 768 instances on.  Per-instance bounds and a per-instance reference
+     * array are served by its "pi" instantiations (kernel name `tile16<...,pi>`): the rows reach LDS by LDS-DMA, one resident row per
+     * instance when the table does not change along the horizon, a ring of step slots otherwise; with fp16 storage, inside a closed-loop
+     * run with per-instance tables, or with per-step per-instance bounds beside a trajectory table too long for the LDS left, the handle
+     * falls back to the auto choice among the 16-lane kernels).  For 16 < nx + nu <= 64 (one wavefront per instance): 6 = wavestream (state in HBM, any
      * N), 7 = waveres (state in registers/LDS, N <= 50; the auto choice up to 2 048 and for 4 097 ... 6 144 instances), 8 = tile48 (nx = 32, nu = 16,
      * N <= 50, fp32 storage: sixteen instances per workgroup as the columns of 16x16 MFMA tiles, duals in LDS;
      * the auto choice for 2 049 ... 4 096 and from 6 145 instances on (rounds of the launch)).  All of them compute identical results. */

@@ -39,6 +39,7 @@ CLASSES = [("quad", 30), ("quad", 25), ("quad", 20), ("quad", 10), ("quad", 17),
 if len(sys.argv) > 3:   # optional third argument: only the classes whose name contains it (e.g. "rand32": the nx = 32 kernels incl. tile48)
     CLASSES = [c for c in CLASSES if sys.argv[3] in c[0]]
 t_end, rounds, solves, t_note, overflowed, refused = time.time() + budget, 0, 0, time.time(), 0, 0
+kernels_seen = {}
 while time.time() < t_end:
     if time.time() - t_note > 30:
         print(f"... {rounds} rounds, {solves} solves so far", flush=True)
@@ -66,6 +67,8 @@ while time.time() < t_end:
     bnds = (xmn, xmx, umn, umx)
     if rng.random() < 0.25:  # per-instance bounds (served by the kernels that stream their state)
         bnds = tuple((a[None] * rng.uniform(0.3, 1.0, size=(B,) + a.shape)).astype(np.float32) for a in bnds)
+        if rng.random() < 0.4:   # ... that do not change along the horizon (admm_tile16_pi.hip keeps one resident row per instance then)
+            bnds = tuple(np.repeat(a[:, :1], a.shape[1], axis=1).copy() for a in bnds)
     bnds_raw = bnds
     sol = T.TinyBatchSolver(prob, B, settings=settings)
     h16 = not wave and rng.random() < 0.3   # fp16 storage / fp32 arithmetic against the oracle's _h16 restatement
@@ -92,7 +95,10 @@ while time.time() < t_end:
     if mode == 0:
         xref = (rng.standard_normal((N, nx)) * 0.3).astype(np.float32); sol.set_xref(xref)
     elif mode == 1:
-        xref = (rng.standard_normal((B, N, nx)) * 0.3).astype(np.float32); sol.set_xref(xref)
+        xref = (rng.standard_normal((B, N, nx)) * 0.3).astype(np.float32)
+        if rng.random() < 0.3:   # every instance its own set point
+            xref = np.repeat(xref[:, :1], N, axis=1).copy()
+        sol.set_xref(xref)
     else:
         table = (rng.standard_normal((N + 40, nx)) * 0.3).astype(np.float32)
         start = rng.integers(0, 40, size=B).astype(np.int32)
@@ -141,6 +147,7 @@ while time.time() < t_end:
             orc.solve(st, *bnds, xref, nthreads=8); solves += 1
         else:
             orc.solve(st, *bnds, xref, nthreads=8); sol.solve(); solves += 1
+            kernels_seen[sol.kernel_name()] = kernels_seen.get(sol.kernel_name(), 0) + 1
         if not all(np.all(np.isfinite(st[n_])) for n_ in O.STATE_ORDER):
             overflowed += 1   # NaN / inf regime (fp16 storage overflow, unstable iteration): behaviour undefined
             break
@@ -178,3 +185,8 @@ while time.time() < t_end:
         hip.hipFree(d_order)
 print(f"fuzz ok: {rounds} rounds, {solves} solves, all bitwise equal to the oracle (signs of zeros included); "
       f"{overflowed} rounds left the finite range and were not compared; {refused} fp32-dual rounds asked for a kernel that does not implement them and were refused")
+fam = {}
+for k, v in kernels_seen.items():   # solves per kernel family (tile16 split into its shared-table and per-instance-table instantiations)
+    key = k.split("<")[0] + (",pi" if k.endswith(",pi>") else "")
+    fam[key] = fam.get(key, 0) + v
+print("solves per kernel:", ", ".join(f"{k} {v}" for k, v in sorted(fam.items())))
