@@ -41,6 +41,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef TINY_T16_ABLATE
 #define TINY_T16_ABLATE 0
 #endif
+#ifndef TINY_T16_CQ
+#define TINY_T16_CQ 1 // the staged reference table holds -(Xref o Q) (round 4): no Q registers and no multiply in the sweeps
+#endif
+#ifndef TINY_T16_BADDR
+#define TINY_T16_BADDR 1 // the lane's bounds-table addresses are remade per iteration instead of being reloaded from scratch (round 4)
+#endif
 #ifndef TINY_T16_SCHED
 #define TINY_T16_SCHED 1 // the scheduling fences pay in exact arithmetic only (measured: exact 2.01 -> 1.88 ms, fma 1.02 -> 1.08)
 #endif
@@ -476,8 +482,16 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
     }
     else
     {
+        // Round 4: the table is staged as cq = -(Xref o Q), the only form the sweeps use (admm.cpp:80-82: the product is one IEEE multiply, the same
+        // bits wherever it is computed; columns 12 .. 15 — the u rows' register — hold -(0 * 1) = -0: r = -rho (znew - y) keeps the sign of a zero
+        // difference).  That takes the four Q registers and two packed multiplies per backward step out of the iteration loop; the raw last row the
+        // terminal term needs is read from memory once per tile.
         for (int e = threadIdx.x; e < tab_rows * 16; e += WAVE * TILE16_WAVES)
-            reinterpret_cast<float *>(&tab[(e >> 4) * 4 + (e & 3)])[(e & 15) >> 2] = tab_src[e];
+        {
+            float val = tab_src[e];
+            if (TINY_T16_CQ) val = -(val * ((e & 15) < NX ? P.mats[(2 * NX + 2 * NU) * 16 + (e & 15)] : 1.f));
+            reinterpret_cast<float *>(&tab[(e >> 4) * 4 + (e & 3)])[(e & 15) >> 2] = val;
+        }
     }
     if constexpr (!BR || !XR) __syncthreads();
 
@@ -489,6 +503,8 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
 #pragma unroll
     for (int v = 0; v < 3; v++) qv[v] = P.mats[(2 * NX + 2 * NU) * 16 + 4 * v + g];
     qv[3] = 1.f;
+    constexpr bool CQ = TINY_T16_CQ && !XR; // what load_xref returns is already -(Xref o Q)
+    auto cost_of = [&](const f32x4 &xr) { return CQ ? xr : -(xr * qv); };
 
     // Persistent waves (round 3): the launch is one workgroup per CU and every wave draws tiles from a queue (an atomic counter
     // behind RowParams::n_unsolved, zeroed by the host with it) until it is empty.  A CU's LDS belongs to its workgroup, so with
@@ -632,9 +648,20 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
         if constexpr (XR) t16_dma_row((onX >> 1) ^ 1u, xsrc, A0.voffX, dmaX, 0.f); // (a resident reference row is never an image)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    // the RAW reference row (the terminal term -(Xref_{N-1}^T Pinf), admm.cpp:83): with the staged table holding -(Xref o Q) it is read from memory
+    auto load_xref_raw = [&](const float4 *tb, int ws, int i) {
+        if constexpr (CQ)
+        {
+            int row = ws + i;
+            row = row < tab_rows ? row : tab_rows - 1;
+            const float *rp = tab_src + row * 16 + g;
+            return f32x4{rp[0], rp[4], rp[8], 0.f};
+        }
+        else return load_xref(tb, ws, i);
+    };
     float pterm[3];
     {
-        const f32x4 xrN4 = load_xref(tab, wstart, N - 1);
+        const f32x4 xrN4 = load_xref_raw(tab, wstart, N - 1);
         const float xrN[3] = {xrN4[0], xrN4[1], xrN4[2]};
         M.terminal(xrN, pterm);
     }
@@ -661,7 +688,7 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
         };
         auto make_lin = [&](int i, const float4 &sl, const f32x4 &xr) {
             const f32x4 sni = {sl.x, sl.y, sl.z, sl.w};
-            return lin_cost4<EXACT>(-(xr * qv), rho4, sni - dual4(i)); // admm.cpp:80-82
+            return lin_cost4<EXACT>(cost_of(xr), rho4, sni - dual4(i)); // admm.cpp:80-82
         };
         float4 sl0; f32x4 xr0;
         load_lin(N - 2, sl0, xr0);
@@ -703,10 +730,16 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
         int oz;
         asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
         float4 *const snI = sn + oz;
-        const float4 *const bloI = blo + oz, *const bhiI = bhi + oz, *const tabI = tab + oz;
+        const float4 *bloI = blo + oz, *bhiI = bhi + oz;
+        const float4 *const tabI = tab + oz;
         const int wsI = wstart + oz;
         const unsigned long long amask = __ballot(active); // instances still iterating: wave-uniform during the forward sweep
         const unsigned sn_addr = (unsigned)(size_t)(lds_float4 *)snI;
+        // the lane's rows of the staged bounds tables ([step][g] float4): g remade from the slack address (16 x lane = sn_addr - the wave's base, g = lane >> 4)
+        // — carried across the iteration in registers of their own the two addresses are spilled, and reloaded from scratch at the head of every
+        // iteration, two vector-memory round trips in front of the first step
+        const unsigned gI = (sn_addr - (unsigned)__builtin_amdgcn_readfirstlane(sn_addr)) >> 8;
+        const float4 *const bloG = bloI + gI, *const bhiG = bhiI + gI;
         // BR / XR rings.  dma_x(i): reference row of step i -> slot i % 3; dma_b(i): {lo, hi} row of step i -> slot i % 3 (two pieces); both skip
         // themselves when their table is one row per instance (fetched at the head of the tile).  `after` = a value that was read from the slot's
         // previous occupant: the refill cannot be issued before that read has returned.
@@ -797,6 +830,7 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
                 t16_wait_vm(2 * ((N - 1 - i) < (DB - 1) ? (N - 1 - i) : (DB - 1))); // the two pieces of step i have landed (newer: steps i + 1 .. i + DB - 1)
                 ring_bounds(i, lo, hi);
             }
+            else if constexpr (TINY_T16_BADDR && (COLD || !XR)) { lo = bloG[i * 4]; hi = bhiG[i * 4]; } // (warm start with the reference ring: 225 against 33)
             else { lo = bloI[i * 4 + g]; hi = bhiI[i * 4 + g]; }
             const float4 ol = snI[i * WAVE];
             typename TileMath<EXACT>::InFlight F;
@@ -842,7 +876,7 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
             };
             auto make_lin = [&](int i, const float4 &sl, const f32x4 &xr) {
                 const f32x4 sni = {sl.x, sl.y, sl.z, sl.w};
-                return lin_cost4<EXACT>(-(xr * qv), rho4, sni - dual4(i)); // admm.cpp:80-82
+                return lin_cost4<EXACT>(cost_of(xr), rho4, sni - dual4(i)); // admm.cpp:80-82
             };
             float4 sl0; f32x4 xr0;
             if constexpr (XR) t16_wait_vm(0); // rows N-2 .. N-1-DX were fetched at the head of the iteration
@@ -923,7 +957,7 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
         if (P.xref_mode == 1)
         {
             wstart += P.window_advance;
-            const f32x4 xrN4 = load_xref(tab + oz, wstart, N - 1);
+            const f32x4 xrN4 = load_xref_raw(tab + oz, wstart, N - 1);
             const float xrN[3] = {xrN4[0], xrN4[1], xrN4[2]};
             M.terminal(xrN, pterm);
         }
@@ -979,7 +1013,7 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
             const f32x4 sv = {s[0], s[1], s[2], un};
             const f32x4 sni = reinterpret_cast<const f32x4_ma *>(stage_w + i * (WAVE * 4))[lane];
             const f32x4 xr = load_xref(tab, wstart, i);
-            f32x4 lin = lin_cost4<EXACT>(-(xr * qv), rho4, sni - dual4(i));
+            f32x4 lin = lin_cost4<EXACT>(cost_of(xr), rho4, sni - dual4(i));
             if (i == N - 1) lin[3] = 0.f;
             // p.col(N-1) is rewritten by every forward sweep (admm.cpp:83-84); the other columns and d come from the
             // last backward sweep this instance executed (an instance that never ran one keeps its live-in p, d)
@@ -1014,7 +1048,7 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
             {
                 const f32x4 sni = reinterpret_cast<const f32x4_ma *>(stage_w + i * (WAVE * 4))[lane];
                 const f32x4 xr = load_xref(tab, wstart, i);
-                const f32x4 lin = lin_cost4<EXACT>(-(xr * qv), rho4, sni - dual4(i));
+                const f32x4 lin = lin_cost4<EXACT>(cost_of(xr), rho4, sni - dual4(i));
                 float pn[3], dd;
                 M.riccati(p, lin, pn, dd);
                 float_ma *slot = stage_w + i * (WAVE * 4);
