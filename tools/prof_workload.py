@@ -25,6 +25,12 @@ WORKLOADS = {
     "rowlane_fast": dict(prob="q30", batch=65536, ref="track", variant=3, family=1),
     "tile16_exact": dict(prob="q30", batch=65536, ref="track", variant=2, family=5),
     "tile16_fast": dict(prob="q30", batch=65536, ref="track", variant=3, family=5),
+    # the headline workload with per-instance tables (admm_tile16_pi.hip): every instance its own bounds (constant along the horizon: one resident row),
+    # its own reference trajectory (per step: a ring fed from the tile image), both per step; and the 16-lane kernel on the same inputs
+    "tile16_pi_bounds_const": dict(prob="q30", batch=65536, ref="track", variant=2, family=5, pi_bounds="const"),
+    "tile16_pi_xref_steps": dict(prob="q30", batch=65536, ref="inst", variant=2, family=5),
+    "tile16_pi_both_steps": dict(prob="q30", batch=65536, ref="inst", variant=2, family=5, pi_bounds="steps"),
+    "rowlane_pi_both_steps": dict(prob="q30", batch=65536, ref="inst", variant=2, family=1, pi_bounds="steps"),
     "rowloop_exact": dict(prob="q17", batch=65536, ref="track", variant=2, family=2),
     "rowstream_exact": dict(prob="q17", batch=65536, ref="track", variant=2, family=3),
     "stream_3_1": dict(prob="q30", batch=65536, ref="track", variant=1, family=0),
@@ -65,7 +71,7 @@ def main():
     nx, nu, N = prob["nx"], prob["nu"], prob["N"]
     settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1, en_state_bound=1, en_input_bound=1)
     settings.update(w.get("settings", {}))
-    if w["ref"] == "track":
+    if w["ref"] in ("track", "inst"):
         x0, table, start = pr.tracking_batch(B, N)
     elif w["prob"] == "cp":
         rng = np.random.default_rng(1)
@@ -94,8 +100,15 @@ def main():
         sol.select_kernel(w["variant"])
         if w["family"]:
             sol.set_row_kernel(w["family"])
-        sol.set_bounds(*pr.bounds_arrays(prob))
-        if w["ref"] == "track":
+        bnds = pr.bounds_arrays(prob)
+        if w.get("pi_bounds"):   # the same values for every instance (the iterates do not change); "steps": one entry differs along the horizon
+            bnds = [np.broadcast_to(a, (B,) + a.shape).copy() for a in bnds]
+            if w["pi_bounds"] == "steps":
+                bnds[1][:, 5, 0] *= 1.0000001
+        sol.set_bounds(*bnds)
+        if w["ref"] == "inst":
+            sol.set_xref(pr.expand_windows(table, start, N))
+        elif w["ref"] == "track":
             sol.set_xref_window(table, start)
         else:
             sol.set_xref(np.zeros((N, nx), np.float32))

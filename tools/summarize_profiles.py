@@ -72,9 +72,11 @@ def label(kname):
         if not rest[0] and not rest[1]:   # the closed-loop and per-instance-bounds instantiations are different workloads
             sto = (",h16d" if rest[2] else ",h16") if m.group(5) == "true" else ""
             return f"rowlane<{m.group(1)},{m.group(2)},{m.group(3)},{'exact' if m.group(4) == 'true' else 'fast'}{sto}>"
-    m = re.search(r"admm_tile16_kernel<(\d+), (true|false), (true|false)>", kname)   # N, EXACT, COLD (nx = 12, nu = 4)
+    m = re.search(r"admm_tile16_kernel<(\d+), (true|false), (true|false)((?:, (?:true|false))*)>", kname)   # N, EXACT, COLD[, MPC, BR, XR] (nx = 12, nu = 4)
     if m:
-        return f"tile16<12,4,{m.group(1)},{'exact' if m.group(2) == 'true' else 'fast'}>"
+        rest = [t.strip() == "true" for t in m.group(4).split(",") if t.strip()] + [False] * 3
+        if not rest[0]:   # the closed-loop instantiation is a different workload
+            return f"tile16<12,4,{m.group(1)},{'exact' if m.group(2) == 'true' else 'fast'}{',pi' if rest[1] or rest[2] else ''}>"
     m = re.search(r"admm_stream_kernel<(\d+), (\d+)>", kname)
     if m:
         return f"stream<{m.group(1)},{m.group(2)}>"
