@@ -47,6 +47,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef TINY_T16_BADDR
 #define TINY_T16_BADDR 1 // the lane's bounds-table addresses are remade per iteration instead of being reloaded from scratch (round 4)
 #endif
+#ifndef TINY_T16_PADTAB
+#define TINY_T16_PADTAB 1 // the staged reference table carries N - 1 copies of its last row: no per-step clamp of the window's row (round 4)
+#endif
 #ifndef TINY_T16_SCHED
 #define TINY_T16_SCHED 1 // the scheduling fences pay in exact arithmetic only (measured: exact 2.01 -> 1.88 ms, fma 1.02 -> 1.08)
 #endif
@@ -486,9 +489,12 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
         // bits wherever it is computed; columns 12 .. 15 — the u rows' register — hold -(0 * 1) = -0: r = -rho (znew - y) keeps the sign of a zero
         // difference).  That takes the four Q registers and two packed multiplies per backward step out of the iteration loop; the raw last row the
         // terminal term needs is read from memory once per tile.
-        for (int e = threadIdx.x; e < tab_rows * 16; e += WAVE * TILE16_WAVES)
+        // ... and carries N - 1 copies of its last row behind it: a window start clamped ONCE to the last row then reads rows ws + i without a per-step
+        // clamp (three vector instructions per backward step: add, min, shift-add in front of the LDS read)
+        for (int e = threadIdx.x; e < (tab_rows + N - 1) * 16; e += WAVE * TILE16_WAVES)
         {
-            float val = tab_src[e];
+            const int er = (e >> 4) < tab_rows ? (e >> 4) : tab_rows - 1;
+            float val = tab_src[er * 16 + (e & 15)];
             if (TINY_T16_CQ) val = -(val * ((e & 15) < NX ? P.mats[(2 * NX + 2 * NU) * 16 + (e & 15)] : 1.f));
             reinterpret_cast<float *>(&tab[(e >> 4) * 4 + (e & 3)])[(e & 15) >> 2] = val;
         }
@@ -612,7 +618,7 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
     const float *const xsrc = P.xref; // XR: the per-instance array (one resident row per instance) or its tile image (ring): row i of the tile at
                                       // ((tile N + i) 64 + lane) 16 bytes
     // Xref_i for this lane: x rows in registers 0..2, register 3 = 0 (column 12 + g of the 16-wide table row)
-    auto load_xref = [&](const float4 *tb, int ws, int i) {
+    auto load_xref = [&](const float4 *tb, int ws, int i, int gsel = -1) { // gsel: the lane's g where the caller has remade it (iteration loop)
         if constexpr (XR) // prologue / epilogue (outside the sweeps): straight from memory
         {
             // (the lane number passes through an opaque statement: the addresses below are then made where they are used — hoisted in front of the
@@ -631,9 +637,12 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
         }
         else
         {
-        int row = ws + i;
-        row = row < tab_rows ? row : tab_rows - 1;
-        const float4 t4 = tb[row * 4 + g];
+        int row;
+        // (same-box A/B, 65 536 tracking instances: warm start 1.78 -> 1.71 ms, fma 0.874 -> 0.860, closed loop on chip 1.040 -> 1.030 / 0.540 -> 0.502; the
+        //  exact cold-start instantiation alone loses 0.8 % — two more scratch accesses per iteration at the allocator's cliff — and keeps the clamp)
+        if constexpr (TINY_T16_PADTAB && !(EXACT && COLD && !MPC && !BR && !XR)) row = (ws < tab_rows - 1 ? ws : tab_rows - 1) + i; // rows wc .. wc + N - 1 exist
+        else { row = ws + i; row = row < tab_rows ? row : tab_rows - 1; }
+        const float4 t4 = tb[row * 4 + (gsel >= 0 ? gsel : g)];
         return f32x4{t4.x, t4.y, t4.z, t4.w};
         }
     };
@@ -872,7 +881,7 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
             auto load_lin = [&](int i, float4 &sl, f32x4 &xr) { // LDS reads of step i's linear cost: issued a step ahead, in front of the MFMAs
                 sl = snI[i * WAVE];
                 if constexpr (XR) xr = ring_xref(i);
-                else xr = load_xref(tabI, wsI, i);
+                else xr = load_xref(tabI, wsI, i, TINY_T16_BADDR ? (int)gI : -1);
             };
             auto make_lin = [&](int i, const float4 &sl, const f32x4 &xr) {
                 const f32x4 sni = {sl.x, sl.y, sl.z, sl.w};
@@ -1092,7 +1101,7 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
 size_t tile16_pi_lds_bytes(int N, bool bounds_ring, bool xref_ring, unsigned pi_flags, int table_rows)
 {
     const size_t bnd = bounds_ring ? (size_t)TILE16_WAVES * ((pi_flags & 1u) ? t16_ring_b(xref_ring) : 2) * T16_RING_B : (size_t)2 * N * 4 * sizeof(float4);
-    const size_t ref = xref_ring ? (size_t)TILE16_WAVES * ((pi_flags & 2u) ? t16_ring_x(bounds_ring) : 1) * T16_RING_X : (size_t)table_rows * 4 * sizeof(float4);
+    const size_t ref = xref_ring ? (size_t)TILE16_WAVES * ((pi_flags & 2u) ? t16_ring_x(bounds_ring) : 1) * T16_RING_X : (size_t)(table_rows + N - 1) * 4 * sizeof(float4);
     return (size_t)TILE16_WAVES * N * WAVE * sizeof(float4) + bnd + ref;
 }
 
@@ -1150,7 +1159,7 @@ hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t
     const int want = (ntiles + TILE16_WAVES - 1) / TILE16_WAVES, nblocks = want < n_cu ? want : n_cu; // one persistent workgroup per CU
     const int rows = P.xref_mode == 1 ? P.table_rows : N;
     if (rows > TILE16_MAX_TABLE_ROWS) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(TILE16_WAVES * N * WAVE + 2 * N * 4 + rows * 4) * sizeof(float4);
+    const size_t lds = (size_t)(TILE16_WAVES * N * WAVE + 2 * N * 4 + (rows + N - 1) * 4) * sizeof(float4); // the staged table is padded with N - 1 copies of its last row
 #define TINY_TILE16_LAUNCH(NN, EX)                                                                                         \
     {                                                                                                                      \
         auto kern = P.mpc_steps > 1 ? (P.cold_start ? admm_tile16_kernel<NN, EX, true, true> : admm_tile16_kernel<NN, EX, false, true>) \

@@ -2190,6 +2190,8 @@ def test_debug_guard_zones_stay_intact(tinympc):
         for B in (1, 17, 203):
             runs += [(q30, B, 2, 1, {}), (q30, B, 3, 1, {}), (q30, B, 2, 2, {}), (q30, B, 2, 3, {}), (q30, B, 2, 5, {}), (q30, B, 3, 5, {}), (q30, B, 1, 0, {}),
                      (q30, B, 2, 1, dict(per_instance_bounds=True)), (q30, B, 2, 0, dict(storage=16)), (q30, B, 2, 1, dict(optional=True)),
+                     # the pi instantiations of tile16 (LDS-DMA slots and rings, tile images): resident bounds row + reference ring; both rings, cold and warm
+                     (q30, B, 2, 5, dict(per_instance_bounds=True)), (q30, B, 3, 5, dict(per_instance_bounds=True, per_step=True)),
                      (q17, B, 2, 0, {}), (q77, B, 2, 0, {}), (cp, B, 2, 0, {}), (cp, B, 2, 1, {}), (odd, B, 2, 0, {}),
                      (r32, B, 2, 6, {}), (r32, B, 2, 7, {}), (r32, B, 2, 8, {}), (r32, B, 3, 8, {}), (r32, B, 1, 0, {}), (gen, B, 0, 0, {}), (q30, B, 4, 0, {})]
         names = set()
@@ -2204,6 +2206,8 @@ def test_debug_guard_zones_stay_intact(tinympc):
             bnds = pr.bounds_arrays(prob)
             if extra.get("per_instance_bounds"):
                 bnds = tuple(np.broadcast_to(a, (B,) + a.shape).copy() for a in bnds)
+                if extra.get("per_step"):
+                    bnds[1][:, N // 2] *= 0.9
             sol.set_bounds(*bnds)
             table = (rng.standard_normal((N + 9, nx)) * 0.1).astype(np.float32)
             start = rng.integers(0, 9, size=B).astype(np.int32)
@@ -2229,6 +2233,7 @@ def test_debug_guard_zones_stay_intact(tinympc):
             sol.close()
         families = {n.split("<")[0] for n in names}
         assert {"rowlane", "rowloop", "rowstream", "quadlane", "tile16", "wavestream", "waveres", "tile48", "stream", "generic"} <= families, families
+        assert {"tile16<12,4,30,exact,pi>", "tile16<12,4,30,fast,pi>"} <= names, names
         # the checker itself: one word written just outside a work array must be counted
         sol = tinympc.TinyBatchSolver(q30, 5)
         for which in (0, 1):
