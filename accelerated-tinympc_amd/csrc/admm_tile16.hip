@@ -381,13 +381,15 @@ constexpr int TILE16_MAX_TABLE_ROWS = 512;
 //     registers the shared tables deliver, so the arithmetic is untouched (tools/micro/glds_ring.hip checks the mapping, a destination above
 //     64 KB in M0 and the counted waits in isolation);
 //   * a table that does not change along the horizon (RowParams::pi_flags bit clear: the usual case — every robot its own limits, its own
-//     set point) is ONE row per instance: fetched once per tile into a single slot, nothing moves inside the iteration loop;
-//   * a table that does (bit set) goes through a ring of three step slots, two steps ahead of its use, retired with counted `s_waitcnt vmcnt`;
-//     a slot is refilled only after the values read from it have been consumed (the DMA statement takes one of them as an operand).  A
-//     DMA costs a lone wave about 30 clocks of issue (M0, one wait state, the instruction): three per step pair are 8 % of it.
+//     set point) is ONE row per instance: fetched once per tile into a resident slot (bounds: two — the last step's input rows are unbounded), nothing
+//     moves inside the iteration loop;
+//   * a table that does (bit set) goes through a ring of 3 - 6 step slots (t16_ring_b / t16_ring_x), fetched depth - 1 steps ahead of its use and
+//     retired with counted `s_waitcnt vmcnt`; a slot is refilled only after the values read from it have been consumed (the DMA statement takes one
+//     of them as an operand).  A DMA costs a lone wave about 30 clocks of issue (M0, one wait state, the instruction): with the tables
+//     L2-resident the reference ring measured + 1.6 %, the bounds ring + 8 %;
 //   * ring tables come from TILE IMAGES (tile16_image_kernel, built when the inputs are set): [tile][step][piece][lane][16 B], i.e. exactly the LDS
 //     image of a slot, so that a DMA reads 1 KB of consecutive bytes in whole 128-byte lines — from the [instance][step][16] arrays the same DMA is
-//     sixteen half lines 1 920 B apart, and a CU's outstanding misses, not the memory, bound the ring (measured: reference ring 1.93 -> … ms).
+//     sixteen half lines 1 920 B apart, and a CU's outstanding misses, not the memory, bound the ring (measured: reference ring 1.93 -> 1.81 ms).
 //     RowParams::bounds / ::xref point to the images then.  (A window of the trajectory table is never read through a ring: with a table too
 //     long for the LDS share beside the bounds' slots the handle keeps the 16-lane kernel.)
 // The other table of a BR-only / XR-only instantiation is the batch-shared one staged in LDS, as in the base kernel.  hipcc does not count an
