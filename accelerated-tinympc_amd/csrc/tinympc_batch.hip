@@ -381,7 +381,8 @@ struct TinyBatch
     InputArr in_uref;                    // [batch or 1][N-1][nu]
     float *r_uref = nullptr;             // ROW derived: [batch_pad4 or 1][N][rw], Uref on the u rows
     const int *order_dev = nullptr;      // caller-owned dispatch order of the instance groups (tiny_batch_set_dispatch_order_device)
-    int dispatch_mode = 0;               // tiny_batch_set_dispatch: 0 in index order, 1 longest first by the predicted iteration count
+    int dispatch_mode = -1;              // tiny_batch_set_dispatch: 0 in index order, 1 longest first by the predicted iteration count, -1 (default) automatic:
+                                         // longest first for a launch that starts from a reset workspace (dispatch_effective)
     float *u0_stage = nullptr;           // [batch][nu] staging of u.col(0) for the peer copy of tiny_batch_group_gather_u0
     float *key_buf = nullptr;            // [groups] predictor of dispatch_order.hip
     int *order_buf = nullptr;            // [groups] its sorted order
@@ -624,6 +625,10 @@ int store_input(TinyBatch *tb, InputArr &in, const float *host, bool shared, int
     tb->derived_dirty[0] = tb->derived_dirty[1] = true; // (a captured closed-loop graph carries the mode in its signature)
     return 0;
 }
+
+// tiny_batch_set_dispatch(-1), the default: the predictor sweep and the sort pay where the iteration counts of a launch spread widely — a launch that starts from a
+// reset workspace (65 536 tracking instances, wall time per solve: 2.20 -> 1.76 ms; 16 384: 0.82 -> 0.68) — and cost 2 - 4 % on warm-started steps (1.62 -> 1.66 ms)
+int dispatch_effective(const TinyBatch *tb) { return tb->dispatch_mode >= 0 ? tb->dispatch_mode : (tb->cold_pending ? 1 : 0); }
 
 bool bounds_all_shared(const TinyBatch *tb)
 {
@@ -892,7 +897,12 @@ int prepare_inputs(TinyBatch *tb, int layout)
 }
 
 int row_family(const TinyBatch *tb);
-constexpr int kTile16AutoBatch = 32768;
+// Automatic choice of the sixteen-instances-per-wave kernel (round 4, re-measured on the final binaries, 65 536-instance tracking workload cut to size, kernel ms,
+// tile16 / 16-lane kernel, both longest first): 32 768: 1.03 / 0.97, 36 864: 1.11 / 1.08, 40 960: 1.09 / 1.19, 49 152: 1.24 / 1.40, 65 536: 1.54 / 1.83 — from 160
+// instances per CU on; in index order the 16-lane kernel wins or ties at every size (65 536: 2.00 / 1.99), so the choice also asks for the longest-first dispatch
+constexpr int kTile16AutoPerCu = 160;
+int dispatch_effective(const TinyBatch *tb);
+bool tile16_auto_size(const TinyBatch *tb) { return dispatch_effective(tb) == 1 && tb->batch >= kTile16AutoPerCu * tb->n_cu; }
 
 // fp16 storage: bring the duals pair to the width the coming launch implements.  Under tiny_batch_set_storage(tb, 16) fp32 duals are a
 // PREFERENCE (the register-resident 16-lane and quad kernels keep them, every other kernel — streamed state, per-instance bounds under
@@ -979,13 +989,11 @@ Tile16Pi tile16_pi_plan(const TinyBatch *tb)
     p.fits = tile16_pi_lds_bytes(tb->N, p.bounds_ring, p.xref_ring, p.flags, rows) <= 160 * 1024; // a staged table too long for the LDS share beside the slots
     return p;
 }
-// automatic choice with per-instance tables (65 536 tracking instances, kernel ms, tile16 pi against the 16-lane kernel): tables that do not change along the
-// horizon 1.71 / 2.08 (bounds), through the rings with the longest-first dispatch 1.98 / 2.08 (bounds), 1.90 / 1.95 (reference), 2.04 / 2.15 (both); in index
-// order the rings lose (2.45 / 2.22): there the 16-lane kernel stays
+// automatic choice with per-instance tables: the same rule as with shared ones (65 536 tracking instances, longest first, kernel ms, tile16 pi against the 16-lane
+// kernel: bounds constant along the horizon 1.75 / 2.13, reference per step 1.81 / 1.96, both per step 1.95 / 2.15; in index order the rings lose, 2.45 / 2.22)
 bool tile16_pi_auto(const TinyBatch *tb)
 {
-    if (tb->order_dev || tb->batch < kTile16AutoBatch) return false;
-    return tile16_pi_plan(tb).flags == 0u || tb->dispatch_mode == 1;
+    return !tb->order_dev && tile16_auto_size(tb);
 }
 bool tile16_applies(const TinyBatch *tb)
 {
@@ -1051,7 +1059,7 @@ int row_family(const TinyBatch *tb)
     // (round 4: tile16's MPC loop stays on chip too — tiny_batch_set_row_kernel(tb, 5) — but the warm-started solves of a closed loop are short and
     //  uneven, and sixteen instances in lock step lose more there than the matrix cores gain: measured 1.02 ms per MPC step of 65 536 tracking
     //  instances against 0.97 ms on the 16-lane kernel, so the automatic choice of a closed-loop run stays with the latter)
-    if (tile16_applies(tb) && !tb->closed_loop_run && !tb->order_dev && tb->batch >= kTile16AutoBatch && (!tile16_per_instance(tb) || tile16_pi_auto(tb))) return 5;
+    if (tile16_applies(tb) && !tb->closed_loop_run && !tb->order_dev && tile16_auto_size(tb)) return 5;
     if (tb->row_dims_ok) return 0;
     if (tb->rowloop_ok) return 1;
     return 2;
@@ -1180,7 +1188,7 @@ int prepare_solve(TinyBatch *tb, int *variant)
     int v = 0;
     TRY(resolve_variant(tb, &v));
     if (tb->gains_dirty) TRY(pack_gains(tb));
-    if (tb->dispatch_mode == 1 && !tb->order_buf)
+    if (dispatch_effective(tb) == 1 && !tb->order_buf)
     {
         TRY(dev_alloc_zero(&tb->key_buf, (size_t)tb->bpad4 / 4 + (size_t)tb->bpad4 / 16 + 16)); // group keys, then tile keys
         TRY(dev_alloc_zero((float **)&tb->order_buf, (size_t)tb->bpad4 / 4));
@@ -1211,7 +1219,7 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
     // longest-first dispatch (dispatch_order.hip): predictor sweep + bucket sort ahead of the register-resident 16-lane kernels;
     // pays off only when the launch is several rounds of waves deep
     const int fam_l = layout == LAYOUT_ROW ? row_family(tb) : -1;
-    const bool predicted_order = layout == LAYOUT_ROW && tb->dispatch_mode == 1 && !tb->order_dev && (fam_l == 0 || fam_l == 1 || fam_l == 5) && !tb->dual32 &&
+    const bool predicted_order = layout == LAYOUT_ROW && dispatch_effective(tb) == 1 && !tb->order_dev && (fam_l == 0 || fam_l == 1 || fam_l == 5) && !tb->dual32 &&
                                  tb->bpad4 / 4 >= kDispatchMinGroups && tb->max_iter > 1;
     // [0] unsolved count, [1] tile queue of admm_tile16.hip: zeroed by the sort kernel of the predicted order where that runs (one stream node less)
     if (!predicted_order) HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, 2 * sizeof(int), tb->stream));
@@ -1380,6 +1388,7 @@ int tiny_batch_create(TinyBatch **out, int nx, int nu, int N, int batch, int dev
     if (int rc = dev_alloc_zero(&tb->staging, tb->staging_floats)) return cleanup(rc);
     if (hipEventCreate(&tb->ev0) != hipSuccess || hipEventCreate(&tb->ev1) != hipSuccess)
         return cleanup(fail(TINY_BATCH_EHIP, "hipEventCreate failed"));
+    tb->cold_pending = true; // a fresh workspace IS a reset one (every array was allocated zero): its first solve is a cold start, like one after tiny_batch_reset_workspace
     update_kname(tb);
     *out = tb;
     return TINY_BATCH_OK;
@@ -1494,7 +1503,7 @@ int tiny_batch_set_uref(TinyBatch *tb, const float *uref, int shared)
 int tiny_batch_set_dispatch(TinyBatch *tb, int mode)
 {
     CHECK_TB(tb);
-    if (mode != 0 && mode != 1) return fail(TINY_BATCH_EINVAL, "tiny_batch_set_dispatch: mode must be 0 (index order) or 1 (longest first, predicted)");
+    if (mode < -1 || mode > 1) return fail(TINY_BATCH_EINVAL, "tiny_batch_set_dispatch: mode must be 0 (index order), 1 (longest first, predicted) or -1 (automatic)");
     tb->dispatch_mode = mode;
     invalidate_graph(tb);
     return 0;

@@ -404,7 +404,8 @@ class TinyBatchSolver:
         self._check(self.lib.tiny_batch_set_row_kernel(self._h, family))
 
     def set_dispatch(self, mode: int):
-        """0 = workgroups in index order, 1 = longest first by a predicted iteration count (register-resident row kernel)."""
+        """0 = workgroups in index order, 1 = longest first by a predicted iteration count (register-resident row kernels), -1 (default) =
+        automatic: longest first for a launch that starts from a reset workspace."""
         self._check(self.lib.tiny_batch_set_dispatch(self._h, mode))
 
     def dispatch_applied(self) -> int:

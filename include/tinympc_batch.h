@@ -229,7 +229,7 @@ extern "C"
      * 2 = rowloop (rolled loops, state in registers/LDS, any N <= 64), 3 = rowstream (any N, state in HBM),
      * 4 = quadlane (4 lanes per instance, nx = 4 and nu = 1 only), 5 = tile16 (16 instances per wavefront as the columns of
      * a 16x16 MFMA tile, gain x state products on the matrix cores in both arithmetic modes, state in registers/LDS; nx = 12,
-     * nu = 4 and an instantiated horizon; the auto choice from 32 768 instances on.  Per-instance bounds and a per-instance reference
+     * nu = 4 and an instantiated horizon; the auto choice for launches dispatched longest first (tiny_batch_set_dispatch) from 160 instances per compute unit on.  Per-instance bounds and a per-instance reference
      * array are served by its "pi" instantiations (kernel name `tile16<...,pi>`): the rows reach LDS by LDS-DMA, one resident row per
      * instance when the table does not change along the horizon, a ring of step slots otherwise; with fp16 storage, inside a closed-loop
      * run with per-instance tables, or with per-step per-instance bounds beside a trajectory table too long for the LDS left, the handle
@@ -262,9 +262,12 @@ extern "C"
 
     /* Dispatch order of the register-resident 16-lane row kernels, unrolled and rolled (a launch of batch/4 workgroups is a
      * few rounds deep and iteration counts are uneven, so what starts last decides when the launch ends; results never depend on the order).
-     * mode 0 (default): index order.  mode 1: longest first by a predicted iteration count — one fma forward sweep over the first
-     * eight horizon steps from the current workspace gives the largest primal residual per group of four instances, a bucket sort orders the groups;
-     * applied to launches of at least 4096 groups, a no-op elsewhere.  The 16-instances-per-wave kernel (tile16) orders its tiles of
+     * mode 0: index order.  mode 1: longest first by a predicted iteration count — one fma forward sweep over the first
+     * four horizon steps from the current workspace gives the largest primal residual per group of four instances, a bucket sort orders the groups;
+     * applied to launches of at least 4096 groups, a no-op elsewhere.  mode -1 (default, round 4): automatic — mode 1 for a launch that starts
+     * from a reset workspace (where the iteration counts spread widely: 2.20 -> 1.76 ms per solve of 65 536 tracking instances), mode 0 for
+     * warm-started ones (where the sweep costs 2 - 4 % and gains nothing).  The automatic kernel choice takes the 16-instances-per-wave kernel only
+     * for launches that are dispatched longest first (from 160 instances per compute unit on: it loses to the 16-lane kernel in index order).  The 16-instances-per-wave kernel (tile16) orders its tiles of
      * sixteen instances by the largest key of their four groups. */
     int tiny_batch_set_dispatch(TinyBatch *tb, int mode);
     /* What the most recent solve launch actually did: 0 = index order (also when mode 1 did not apply: small launch, a kernel

@@ -2787,6 +2787,44 @@ def test_tile16_persistent_queue_at_full_size_equals_row_kernel_bitwise(tinympc,
     assert res[5][0]["iter"].max() >= 30 and res[5][0]["iter"].min() < 20  # the batch really is uneven: waves take different numbers of tiles
 
 
+def test_automatic_dispatch_and_kernel_choice_follow_the_kind_of_launch(tinympc):
+    """tiny_batch_set_dispatch(-1), the default since round 4: a launch that starts from a reset (or fresh) workspace is dispatched longest first —
+    and, from 160 instances per compute unit on, goes to the sixteen-instances-per-wave kernel, which wins only in that order —; a warm-started
+    one keeps index order and the 16-lane kernel.  An explicit mode overrides both ways.  None of it changes a bit of the results."""
+    pr = tinympc.problems
+    prob = pr.quadrotor(20, 30)
+    B = 65536
+    x0, table, start = pr.tracking_batch(B, 30)
+    outs = {}
+    for mode in (None, 0, 1):
+        sol = tinympc.TinyBatchSolver(prob, B)
+        sol.set_bounds(*pr.bounds_arrays(prob)); sol.set_xref_window(table, start)
+        if mode is not None:
+            sol.set_dispatch(mode)
+        want_cold = "rowlane<12,4,30,exact>" if mode == 0 else "tile16<12,4,30,exact>"
+        assert sol.kernel_name() == want_cold, (mode, sol.kernel_name())          # a fresh handle is a reset one
+        sol.set_x0(x0); sol.solve()
+        assert sol.dispatch_applied() == (0 if mode == 0 else 1), (mode, sol.dispatch_applied())
+        cold = sol.get_u()
+        want_warm = "tile16<12,4,30,exact>" if mode == 1 else "rowlane<12,4,30,exact>"
+        assert sol.kernel_name() == want_warm, (mode, sol.kernel_name())          # the next launch is warm-started
+        sol.set_x0(x0 * np.float32(0.98)); sol.reset_dual_variables(); sol.solve()
+        assert sol.dispatch_applied() == (1 if mode == 1 else 0), (mode, sol.dispatch_applied())
+        warm = sol.get_u()
+        sol.reset_workspace()
+        assert sol.kernel_name() == want_cold, (mode, sol.kernel_name())
+        outs[mode] = (cold, warm, sol.get_status()[0])
+        sol.close()
+    for mode in (0, 1):
+        assert np.array_equal(outs[None][0], outs[mode][0]) and np.array_equal(outs[None][1], outs[mode][1]), mode
+    with pytest.raises(tinympc.TinyBatchError):
+        s2 = tinympc.TinyBatchSolver(prob, 8)
+        try:
+            s2.set_dispatch(2)
+        finally:
+            s2.close()
+
+
 @pytest.mark.parametrize("N", [10, 20, 25])
 def test_tile16_other_horizons_equal_the_row_kernel_bitwise(tinympc, N):
     """admm_tile16.hip is instantiated for the quadrotor horizons 10, 20, 25 and 30 (those whose slack fits its LDS share): each
