@@ -50,6 +50,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef TINY_T16_PADTAB
 #define TINY_T16_PADTAB 1 // the staged reference table carries N - 1 copies of its last row: no per-step clamp of the window's row (round 4)
 #endif
+#ifndef TINY_T16_XPOSE
+#define TINY_T16_XPOSE 1 // live-out rows transposed across the four lane groups in registers (v_permlane32_swap / v_permlane16_swap) instead of through LDS (round 4)
+#endif
 #ifndef TINY_T16_SCHED
 #define TINY_T16_SCHED 1 // the scheduling fences pay in exact arithmetic only (measured: exact 2.01 -> 1.88 ms, fma 1.02 -> 1.08)
 #endif
@@ -366,6 +369,21 @@ __device__ __forceinline__ f32x4 lin_cost4(const f32x4 &cq, const f32x4 &rho4, c
 {
     if constexpr (EXACT) return cq - rho4 * t1;
     else return __builtin_elementwise_fma(-rho4, t1, cq);
+}
+
+// Live-out (round 4): lane (g, c) holds elements {4v + g : v = 0..3} of its instance's 64-byte step row in four registers; the row wants
+// elements 4g .. 4g + 3 in ONE lane — the transpose of the 4 x 4 matrix (register v, lane group g).  Two butterfly stages do it in the
+// registers: v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of its second (bit 1 of v <-> bit 1 of g),
+// v_permlane16_swap the odd 16-lane rows of the first with the even rows of the second (bit 0 <-> bit 0).  Four instructions per 4-vector,
+// against a ds_write_b128, four ds_read_b32 and two waits through the slack slot (round 3).
+__device__ __forceinline__ f32x4 t16_transpose4(const f32x4 &r)
+{
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 a = __builtin_amdgcn_permlane32_swap(__float_as_uint(r[0]), __float_as_uint(r[2]), false, false);
+    const u32x2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(r[1]), __float_as_uint(r[3]), false, false);
+    const u32x2 lo = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+    const u32x2 hi = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+    return f32x4{__uint_as_float(lo[0]), __uint_as_float(lo[1]), __uint_as_float(hi[0]), __uint_as_float(hi[1])};
 }
 
 constexpr int TILE16_WAVES = 4;         // waves per workgroup = one per SIMD of a CU; they share the bounds and reference tables
@@ -1005,7 +1023,17 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
         typedef f32x4 f32x4_ma __attribute__((may_alias));
         float_ma *const stage_w = reinterpret_cast<float_ma *>(lds4 + wv * (N * WAVE));     // wave's slack area, as floats
         const int rd_off = (c2 * 4 + q2);                                                    // + 64 * r floats, r = 0..3
+        const int obase4 = ebase + 3 * g; // element 4g of the lane's own instance: ebase = (inst_a N) 16 + g
+        // (the exact warm-start instantiations keep the LDS path: with the register transpose their iteration loop falls off the allocator's cliff,
+        //  600 - 800 scratch accesses per iteration on the listing, where every other instantiation drops to 0 - 1)
+        constexpr bool XPOSE = TINY_T16_XPOSE && !(EXACT && !COLD && !MPC);
         auto put = [&](float *dst, int i, const f32x4 &val) {
+            if constexpr (XPOSE)
+            {
+                const f32x4 o = t16_transpose4(val); // elements 4g .. 4g + 3 of instance c
+                if (valid) *reinterpret_cast<f32x4 *>(dst + obase4 + i * 16) = o;
+                return;
+            }
             float_ma *slot = stage_w + i * (WAVE * 4);
             reinterpret_cast<f32x4_ma *>(slot)[lane] = val;                                  // lane (g, c): elements 4v + g at [lane][v]
             asm volatile("" ::: "memory"); // the reads below fetch what OTHER lanes just wrote: nothing may move across (hipcc
@@ -1044,7 +1072,7 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
             put(P.vz, i, vzv);
             put(P.vzn, i, sni);
             put(P.gy, i, dual4(i));
-            reinterpret_cast<f32x4_ma *>(stage_w + i * (WAVE * 4))[lane] = sni; // the slot gets its slack back: the deferred sweep below reads it
+            if constexpr (!XPOSE) reinterpret_cast<f32x4_ma *>(stage_w + i * (WAVE * 4))[lane] = sni; // the slot gets its slack back: the deferred sweep below reads it
             s[0] = xn[0]; s[1] = xn[1]; s[2] = xn[2];
         }
         // The deferred backward sweep of the last permitted iteration (admm.cpp:141-144 with iter = max_iter): instances that
@@ -1062,6 +1090,13 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
                 const f32x4 lin = lin_cost4<EXACT>(cost_of(xr), rho4, sni - dual4(i));
                 float pn[3], dd;
                 M.riccati(p, lin, pn, dd);
+                if constexpr (XPOSE)
+                {
+                    const f32x4 o = t16_transpose4(f32x4{pn[0], pn[1], pn[2], dd});
+                    if (valid && !solved) *reinterpret_cast<f32x4 *>(P.pd + obase4 + i * 16) = o;
+                }
+                else
+                {
                 float_ma *slot = stage_w + i * (WAVE * 4);
                 reinterpret_cast<f32x4_ma *>(slot)[lane] = f32x4{pn[0], pn[1], pn[2], dd};
                 asm volatile("" ::: "memory");
@@ -1069,6 +1104,7 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
                 o[0] = slot[rd_off]; o[1] = slot[rd_off + 64]; o[2] = slot[rd_off + 128]; o[3] = slot[rd_off + 192];
                 asm volatile("" ::: "memory");
                 if (unsolved2) *reinterpret_cast<f32x4 *>(P.pd + obase2 + i * 16) = o;
+                }
                 p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
             }
         }

@@ -903,6 +903,11 @@ int row_family(const TinyBatch *tb);
 constexpr int kTile16AutoPerCu = 160;
 int dispatch_effective(const TinyBatch *tb);
 bool tile16_auto_size(const TinyBatch *tb) { return dispatch_effective(tb) == 1 && tb->batch >= kTile16AutoPerCu * tb->n_cu; }
+// ... and for a closed-loop run (tiny_batch_mpc_run_async: all MPC steps of a tile inside one launch, index order): since the live-out rows are transposed in
+// registers the MPC instantiation keeps 1 scratch access per iteration instead of 15, and the warm-started tracking loop measures, ms per MPC step, tile16 / 16-lane
+// kernel: 32 768: 0.62 / 0.59, 49 152: 0.84 / 0.80, 65 536: 0.96 / 1.02, 98 304: 1.33 / 1.49, 131 072: 1.73 / 1.95 — from 240 instances per CU on
+constexpr int kTile16ClosedLoopPerCu = 240;
+bool tile16_closed_loop_size(const TinyBatch *tb) { return tb->batch >= kTile16ClosedLoopPerCu * tb->n_cu; }
 
 // fp16 storage: bring the duals pair to the width the coming launch implements.  Under tiny_batch_set_storage(tb, 16) fp32 duals are a
 // PREFERENCE (the register-resident 16-lane and quad kernels keep them, every other kernel — streamed state, per-instance bounds under
@@ -1059,7 +1064,7 @@ int row_family(const TinyBatch *tb)
     // (round 4: tile16's MPC loop stays on chip too — tiny_batch_set_row_kernel(tb, 5) — but the warm-started solves of a closed loop are short and
     //  uneven, and sixteen instances in lock step lose more there than the matrix cores gain: measured 1.02 ms per MPC step of 65 536 tracking
     //  instances against 0.97 ms on the 16-lane kernel, so the automatic choice of a closed-loop run stays with the latter)
-    if (tile16_applies(tb) && !tb->closed_loop_run && !tb->order_dev && tile16_auto_size(tb)) return 5;
+    if (tile16_applies(tb) && !tb->order_dev && (tb->closed_loop_run ? tile16_closed_loop_size(tb) : tile16_auto_size(tb))) return 5;
     if (tb->row_dims_ok) return 0;
     if (tb->rowloop_ok) return 1;
     return 2;

@@ -516,23 +516,28 @@ def main():
             closed = {"kernel": sol.closed_loop_kernel_name(), "mpc_steps": ksteps, "ms_per_mpc_step": dt_c / ksteps * 1e3, "solves_per_s": B * ksteps / dt_c,
                       "mean_iters_last_step": float(itc.mean()), "frac_converged_last_step": float(np.mean(stc == 1)),
                       "note": "warm-started tracking loop on the device (tiny_batch_mpc_run_async: one launch, state on chip between solves), wall time"}
-            # the same loop forced onto the headline kernel, whose MPC loop stays on chip too (round 4): for the record — sixteen instances in
-            # lock step lose more on short warm-started solves than the matrix cores gain, so the automatic choice above is the 16-lane kernel
-            try:
-                sol.set_row_kernel(5)
-                sol.reset_workspace()
-                sol._check(lib.tiny_batch_set_x0_device(h, C.c_void_p(d_x0.data_ptr())))
-                sol.set_xref_window(table, gstart[lo:hi])
-                sol.mpc_run_async(ksteps, 1)
-                sol.synchronize()
-                k16 = sol.closed_loop_kernel_name()
-                t_c = time.perf_counter()
-                sol.mpc_run_async(ksteps, 1)
-                sol.synchronize()
-                dt_16 = time.perf_counter() - t_c
-                closed["on_headline_kernel"] = {"kernel": k16, "ms_per_mpc_step": dt_16 / ksteps * 1e3, "solves_per_s": B * ksteps / dt_16}
-            except Exception as e:  # noqa: BLE001
-                closed["on_headline_kernel"] = {"error": f"{type(e).__name__}: {e}"}
+            # the same loop forced onto the other of the two kernels whose MPC loop stays on chip (round 4), for the record: the automatic choice is the
+            # sixteen-instances-per-wave kernel from 240 instances per compute unit on (measured cross-over), the 16-lane kernel below
+            other = 1 if closed["kernel"].startswith("tile16") else 5
+            for key, fam_k in (("on_headline_kernel", 5), ("on_16_lane_kernel", 1)):
+                if fam_k != other:
+                    closed[key] = {"kernel": closed["kernel"], "ms_per_mpc_step": closed["ms_per_mpc_step"], "solves_per_s": closed["solves_per_s"], "note": "the automatic choice"}
+                    continue
+                try:
+                    sol.set_row_kernel(fam_k)
+                    sol.reset_workspace()
+                    sol._check(lib.tiny_batch_set_x0_device(h, C.c_void_p(d_x0.data_ptr())))
+                    sol.set_xref_window(table, gstart[lo:hi])
+                    sol.mpc_run_async(ksteps, 1)
+                    sol.synchronize()
+                    k16 = sol.closed_loop_kernel_name()
+                    t_c = time.perf_counter()
+                    sol.mpc_run_async(ksteps, 1)
+                    sol.synchronize()
+                    dt_16 = time.perf_counter() - t_c
+                    closed[key] = {"kernel": k16, "ms_per_mpc_step": dt_16 / ksteps * 1e3, "solves_per_s": B * ksteps / dt_16}
+                except Exception as e:  # noqa: BLE001
+                    closed[key] = {"error": f"{type(e).__name__}: {e}"}
             sol.set_row_kernel(0)
         except Exception as e:  # noqa: BLE001
             closed = {"error": f"{type(e).__name__}: {e}"}

@@ -191,8 +191,9 @@ extern "C"
     /* Name of the kernel variant the next solve will launch ("rowlane<12,4,30,exact>", "rowstream<12,4,fast>",
      * "stream<3,1>", with ",h16" appended under fp16 storage). */
     const char *tiny_batch_kernel_name(TinyBatch *tb);
-    /* ... and of the kernel a closed-loop run of several steps (tiny_batch_mpc_run_async) launches, which can differ: the automatic choice
-     * keeps the 16-lane kernel, whose MPC loop stays on chip, where a lone solve of the same batch goes to the matrix-core kernel. */
+    /* ... and of the kernel a closed-loop run of several steps (tiny_batch_mpc_run_async) launches, which can differ: both the 16-lane kernel and the
+     * matrix-core kernel keep their MPC loop on chip; the automatic choice takes the latter from 240 instances per compute unit on (measured cross-over)
+     * with batch-shared bounds, the former below that and with per-instance tables. */
     const char *tiny_batch_closed_loop_kernel_name(TinyBatch *tb);
     /* Debug guard zones (the stand-in for a GPU address sanitizer, which this platform does not offer).
      * tiny_batch_debug_guards(1): every device allocation this library makes FROM NOW ON carries 1 KB of quiet-NaN guard words at

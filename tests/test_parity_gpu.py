@@ -2813,10 +2813,16 @@ def test_automatic_dispatch_and_kernel_choice_follow_the_kind_of_launch(tinympc)
         warm = sol.get_u()
         sol.reset_workspace()
         assert sol.kernel_name() == want_cold, (mode, sol.kernel_name())
+        # a closed-loop run (all MPC steps of a tile inside one launch) takes the sixteen-instances-per-wave kernel from 240 instances per compute unit on
+        assert sol.closed_loop_kernel_name() == "tile16<12,4,30,exact>", sol.closed_loop_kernel_name()
         outs[mode] = (cold, warm, sol.get_status()[0])
         sol.close()
     for mode in (0, 1):
         assert np.array_equal(outs[None][0], outs[mode][0]) and np.array_equal(outs[None][1], outs[mode][1]), mode
+    small = tinympc.TinyBatchSolver(prob, 32768)
+    small.set_bounds(*pr.bounds_arrays(prob)); small.set_xref_window(table, start[:32768])
+    assert small.kernel_name() == "rowlane<12,4,30,exact>" and small.closed_loop_kernel_name() == "rowlane<12,4,30,exact>", (small.kernel_name(), small.closed_loop_kernel_name())
+    small.close()
     with pytest.raises(tinympc.TinyBatchError):
         s2 = tinympc.TinyBatchSolver(prob, 8)
         try:
