@@ -33,6 +33,7 @@
 // Scope: shared box bounds, reference = window of a trajectory table or one shared reference (a per-instance reference
 // array would have to stay resident: the row kernels serve that), fp32 storage, one solve per launch.
 #include "rowlane_math.h"
+#include <cstdlib>
 
 namespace tinympc
 {
@@ -537,12 +538,35 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
     // one tile per wave the CU could not start new work before the slowest of its four tiles had ended; now a wave that finishes
     // takes the next tile at once, and the tables above are staged once per CU instead of once per four tiles.  Tiles are taken
     // in queue order = dispatch order: slot k is tile order[k] (longest predicted first) or tile k.
+    // Two-ended queue (round 4, second session): under longest-first dispatch a launch of q tiles per wave slot ends in a partial round — the
+    // slots all come back from their q-th tile at about the same time and the few tiles left keep a sixth of the chip busy for one more tile's
+    // length (tests/fuzz/sim_tile_deque.py on the true iteration counts: makespan 132.5 iterations against 113.8 of work per slot).  Every
+    // `tail_stride`-th wave therefore takes its tiles from the SHORT end of the order: it fits one tile more into the same time, the partial round
+    // disappears (123).  Head and tail counts share one word (low / high 16 bits, one atomic claims from either end; a claim is good while
+    // head + tail < ntiles); tail_stride = 0 is the plain counter.  The host (t16_tail_stride) decides; results do not depend on it.
+    // (ONE scalar lives across the tile loop for this — the wave's increment; the pi instantiations sit at the allocator's cliff and two more
+    //  sent their iteration loops to scratch.  The decode goes by the tile count, which the loop holds anyway: up to 32 768 tiles the word is
+    //  read as two halves — with no wave at the short end the high half stays zero — beyond that it is the plain counter, and the host sets no stride.)
+    constexpr bool DQ = COLD && !MPC; // longest-first dispatch is the default of launches from a reset workspace: the other instantiations keep the plain counter
+    int qinc = 1;
+    if constexpr (DQ)
+    {
+        const unsigned tail_stride = (P.pi_flags >> 8) & 0xffu;
+        if (tail_stride && (((unsigned)blockIdx.x * TILE16_WAVES + (unsigned)wv) % tail_stride) == 0u) qinc = 0x10000;
+        qinc = __builtin_amdgcn_readfirstlane(qinc);
+    }
     for (;;)
     {
     int slot = 0;
-    if (lane == 0) slot = atomicAdd(P.n_unsolved + 1, 1);
+    if (lane == 0) slot = atomicAdd(P.n_unsolved + 1, qinc);
     slot = __builtin_amdgcn_readfirstlane(slot);
-    if (slot >= ntiles) break; // every wave reaches this: the queue only grows
+    if (DQ && ntiles <= 32768)
+    {
+        const int qh = slot & 0xffff, qt = (int)((unsigned)slot >> 16);
+        if (qh + qt >= ntiles) break; // every wave reaches this: the queue only grows
+        slot = qinc == 1 ? qh : ntiles - 1 - qt;
+    }
+    else if (slot >= ntiles) break;
     // (an opaque zero per tile in every LDS base address: they are invariant across tiles and hipcc would otherwise hoist the
     // per-step addresses of prologue and epilogue out of the queue loop and spill them, as it would inside the iteration loop)
     int ozt;
@@ -1133,6 +1157,22 @@ __global__ __launch_bounds__(WAVE * TILE16_WAVES, 1) void admm_tile16_kernel(con
 #define TINY_FOR_EACH_TILE16(X) X(30) X(25) X(20) X(10)
 #endif
 
+// Which waves take their tiles from the short end of a longest-first order (the kernel's two-ended queue; 0 = none, k = every k-th wave).
+// Measured by replaying the true iteration counts of tracking batches (tests/fuzz/sim_tile_deque.py): with every 8th wave at the short end the
+// makespan of q = 3 / 4 / 6 / 8 tiles per slot drops 8.6 / 7.2 / 4.5 / 2.7 %; at q = 2.5 no slot can fit a tile more and the mid-sized tiles
+// left for last cost 2 %, and in index order (no predictor: warm-started steps, the on-chip closed loop) both ends are alike.  So: a predictor's
+// order, one solve per launch, at least three tiles per wave slot, and a tile count the two 16-bit halves of the queue word can hold.
+// tiny_batch_set_tile_queue(tb, k) / TINYMPC_T16_TAIL=<k> override (0 = plain counter) for A/B runs and tests.
+static inline unsigned t16_tail_stride(const RowParams &P, int ntiles, int nblocks, int asked)
+{
+    static const int env = [] { const char *e = getenv("TINYMPC_T16_TAIL"); return e ? atoi(e) : -1; }();
+    const int forced = asked >= 0 ? asked : env; // tiny_batch_set_tile_queue, then the environment
+    if (ntiles > 32768) return 0u; // head and tail counts overshoot by at most one failed claim per wave
+    if (forced >= 0) return (P.cold_start && P.mpc_steps <= 1) ? (unsigned)(forced > 255 ? 255 : forced) : 0u;
+    if (!P.order || P.mpc_steps > 1 || !P.cold_start) return 0u; // (the kernel's cold-start instantiations carry the two-ended queue)
+    return ntiles >= 3 * nblocks * TILE16_WAVES ? 8u : 0u;
+}
+
 #ifdef TINY_T16_PI_UNIT
 // the PI instantiations are a translation unit of their own (admm_tile16_pi.hip includes this file): they compile beside the others, and the
 // device code of the shared-table instantiations — to which the recorded HBM traffic figures are bound (build.device_isa_sha) — does not move
@@ -1143,7 +1183,7 @@ size_t tile16_pi_lds_bytes(int N, bool bounds_ring, bool xref_ring, unsigned pi_
     return (size_t)TILE16_WAVES * N * WAVE * sizeof(float4) + bnd + ref;
 }
 
-hipError_t launch_admm_tile16_pi(int N, bool exact, bool bounds_ring, bool xref_ring, const RowParams &P, hipStream_t stream, int n_cu)
+hipError_t launch_admm_tile16_pi(int N, bool exact, bool bounds_ring, bool xref_ring, const RowParams &P, hipStream_t stream, int n_cu, int tail)
 {
     const int ntiles = (P.batch + 15) / 16;
     if (n_cu <= 0) n_cu = 256;
@@ -1155,12 +1195,14 @@ hipError_t launch_admm_tile16_pi(int N, bool exact, bool bounds_ring, bool xref_
     if (xref_ring && P.xref_mode == 1) return hipErrorInvalidValue; // a window of the trajectory table is staged, never read through the slots
     const size_t lds = tile16_pi_lds_bytes(N, bounds_ring, xref_ring, P.pi_flags, P.xref_mode == 1 ? P.table_rows : N);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    RowParams Q = P;
+    Q.pi_flags = (Q.pi_flags & 0xffu) | (t16_tail_stride(P, ntiles, nblocks, tail) << 8);
 #define TINY_TILE16_PI_LAUNCH3(NN, EX, BRR, XRR)                                                                           \
     {                                                                                                                      \
         auto kern = P.cold_start ? admm_tile16_kernel<NN, EX, true, false, BRR, XRR> : admm_tile16_kernel<NN, EX, false, false, BRR, XRR>; \
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         if (e != hipSuccess) return e;                                                                                     \
-        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WAVE * TILE16_WAVES), lds, stream, P);                                \
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WAVE * TILE16_WAVES), lds, stream, Q);                                \
         return hipGetLastError();                                                                                          \
     }
 #define TINY_TILE16_PI_LAUNCH(NN, EX)                                             \
@@ -1190,7 +1232,7 @@ bool tile16_supported(int nx, int nu, int N)
 
 int tile16_max_table_rows() { return TILE16_MAX_TABLE_ROWS; }
 
-hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t stream, int n_cu)
+hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t stream, int n_cu, int tail)
 {
     const int ntiles = (P.batch + 15) / 16;
     if (n_cu <= 0) n_cu = 256; // the caller passes the CU count of the handle's device
@@ -1198,13 +1240,15 @@ hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t
     const int rows = P.xref_mode == 1 ? P.table_rows : N;
     if (rows > TILE16_MAX_TABLE_ROWS) return hipErrorInvalidValue;
     const size_t lds = (size_t)(TILE16_WAVES * N * WAVE + 2 * N * 4 + (rows + N - 1) * 4) * sizeof(float4); // the staged table is padded with N - 1 copies of its last row
+    RowParams Q = P;
+    Q.pi_flags = (Q.pi_flags & 0xffu) | (t16_tail_stride(P, ntiles, nblocks, tail) << 8);
 #define TINY_TILE16_LAUNCH(NN, EX)                                                                                         \
     {                                                                                                                      \
         auto kern = P.mpc_steps > 1 ? (P.cold_start ? admm_tile16_kernel<NN, EX, true, true> : admm_tile16_kernel<NN, EX, false, true>) \
                                     : (P.cold_start ? admm_tile16_kernel<NN, EX, true> : admm_tile16_kernel<NN, EX, false>); \
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         if (e != hipSuccess) return e;                                                                                     \
-        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WAVE * TILE16_WAVES), lds, stream, P);                                \
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WAVE * TILE16_WAVES), lds, stream, Q);                                \
         return hipGetLastError();                                                                                          \
     }
 #define TINY_TILE16_DISPATCH(NN)                  \

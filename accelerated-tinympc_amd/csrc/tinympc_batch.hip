@@ -396,6 +396,7 @@ struct TinyBatch
     size_t r_xref_n = 0, r_bounds_n = 0, r_uref_n = 0;    // their allocated sizes in floats (sized_buffer)
     int graph_captures = 0;                               // closed-loop graphs captured so far (tiny_batch_debug_graph_captures)
     int n_cu = 256;                                       // compute units of the handle's device
+    int tile_queue = -1;                                  // tiny_batch_set_tile_queue: -1 automatic, 0 plain counter, k every k-th wave from the short end
     float *tab_tile = nullptr, *tab_row = nullptr;        // trajectory table in both forms
     float *tab_row_h = nullptr;                           // ... and [rows][16] binary16 for fp16 storage
     int table_rows = 0;
@@ -1085,7 +1086,7 @@ hipError_t launch_tile16_pi(const TinyBatch *tb, bool exact, RowParams &P)
         if (!tb->r_xref_img) return hipErrorInvalidValue;
         P.xref = tb->r_xref_img;
     }
-    return launch_admm_tile16_pi(tb->N, exact, pl.bounds_ring, pl.xref_ring, P, tb->stream, tb->n_cu);
+    return launch_admm_tile16_pi(tb->N, exact, pl.bounds_ring, pl.xref_ring, P, tb->stream, tb->n_cu, tb->tile_queue);
 }
 
 void update_kname(TinyBatch *tb)
@@ -1277,7 +1278,7 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
             : fam == 3 ? launch_admm_wavestream(tb->nx, tb->nu, P, tb->stream)
             : fam == 4 ? launch_admm_quadlane(tb->N, v == VAR_ROW_EXACT, tb->h16, P, tb->stream)
             : fam == 5 ? (tile16_per_instance(tb) ? launch_tile16_pi(tb, v == VAR_ROW_EXACT, P)
-                                                  : launch_admm_tile16(tb->N, v == VAR_ROW_EXACT, P, tb->stream, tb->n_cu))
+                                                  : launch_admm_tile16(tb->N, v == VAR_ROW_EXACT, P, tb->stream, tb->n_cu, tb->tile_queue))
             : fam == 6 ? launch_admm_waveres(tb->nx, tb->nu, v == VAR_ROW_EXACT, P, tb->stream)
             : fam == 7 ? launch_admm_tile48(tb->N, v == VAR_ROW_EXACT, P, tb->stream)
                        : launch_admm_rowstream(tb->nx, tb->nu, v == VAR_ROW_EXACT, tb->h16, P, tb->stream);
@@ -1512,6 +1513,15 @@ int tiny_batch_set_dispatch(TinyBatch *tb, int mode)
     tb->dispatch_mode = mode;
     invalidate_graph(tb);
     return 0;
+}
+
+int tiny_batch_set_tile_queue(TinyBatch *tb, int stride)
+{
+    CHECK_TB(tb);
+    if (stride < -1 || stride > 255) return fail(TINY_BATCH_EINVAL, "tiny_batch_set_tile_queue: stride must be -1 (automatic), 0 (one counter) or 1 .. 255");
+    tb->tile_queue = stride;
+    invalidate_graph(tb);
+    return TINY_BATCH_OK;
 }
 
 int tiny_batch_dispatch_applied(TinyBatch *tb)

@@ -88,7 +88,8 @@ struct RowParams
     float *xu, *qr, *pd, *vz, *vzn, *gy;
     const float *xref;           // [batch or 1][N][16]
     unsigned xref_inst_stride;   // floats between instances (0 = shared)
-    unsigned pi_flags;           // admm_tile16_pi.hip only (fills a padding hole: no other kernel's argument layout moves).  bit 0: the {lo, hi} rows differ
+    unsigned pi_flags;           // admm_tile16*.hip only (fills a padding hole: no other kernel's argument layout moves).  bits 8-15: the launcher's tail stride of the
+                                 // two-ended tile queue.  bit 0: the {lo, hi} rows differ
                                  // from step to step (`bounds` is then their tile image, read through a ring of step slots; clear = one row per instance, fetched
                                  // once per tile from the [B][N][16] table), bit 1: the same for the reference rows and `xref`
     const float *xref_table;     // [rows][16]
@@ -142,12 +143,13 @@ hipError_t launch_admm_quadlane(int N, bool exact, bool h16, const RowParams &P,
 // sixteen-instances-per-wave register-resident kernel with the products on the matrix cores (admm_tile16.hip): nx = 12, nu = 4,
 // instantiated horizons; ROW layout and RowParams of the row kernels; shared bounds, window / shared reference, fp32 storage
 bool tile16_supported(int nx, int nu, int N);
-hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t stream, int n_cu);
+// tail: the kernel's two-ended tile queue — -1 automatic (t16_tail_stride), 0 plain counter, k: every k-th wave takes tiles from the short end of the order
+hipError_t launch_admm_tile16(int N, bool exact, const RowParams &P, hipStream_t stream, int n_cu, int tail = -1);
 // the same kernel with the bounds and / or the reference PER INSTANCE ([B][N][16] tables fetched by LDS-DMA into per-wave rings; a shared table or a
 // window goes through the same rings): one solve per launch (admm_tile16_pi.hip)
 // bounds_ring / xref_ring: the table goes through the per-wave LDS-DMA slots (per instance, or a window too long for the LDS share); otherwise it is
 // the batch-shared table staged in LDS as in launch_admm_tile16.  P.pi_flags says which of the ring tables change along the horizon.
-hipError_t launch_admm_tile16_pi(int N, bool exact, bool bounds_ring, bool xref_ring, const RowParams &P, hipStream_t stream, int n_cu);
+hipError_t launch_admm_tile16_pi(int N, bool exact, bool bounds_ring, bool xref_ring, const RowParams &P, hipStream_t stream, int n_cu, int tail = -1);
 size_t tile16_pi_lds_bytes(int N, bool bounds_ring, bool xref_ring, unsigned pi_flags, int table_rows);
 int tile16_max_table_rows(); // rows of a trajectory table that fit the kernel's LDS share
 

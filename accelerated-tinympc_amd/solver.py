@@ -76,7 +76,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
         "tiny_batch_enable_timing": [P, C.c_int], "tiny_batch_last_solve_ms": [P, F],
         "tiny_batch_select_kernel": [P, C.c_int], "tiny_batch_arithmetic": [P], "tiny_batch_debug_graph_captures": [P], "tiny_batch_set_storage": [P, C.c_int], "tiny_batch_set_storage_ex": [P, C.c_int, C.c_int],
         "tiny_batch_set_row_kernel": [P, C.c_int],
-        "tiny_batch_set_dispatch": [P, C.c_int], "tiny_batch_set_dispatch_order_device": [P, P], "tiny_batch_dispatch_applied": [P],
+        "tiny_batch_set_dispatch": [P, C.c_int], "tiny_batch_set_tile_queue": [P, C.c_int], "tiny_batch_set_dispatch_order_device": [P, P], "tiny_batch_dispatch_applied": [P],
         "tiny_batch_set_optional_terms": [P, C.c_int, C.c_int], "tiny_batch_set_input_cost": [P, F],
         "tiny_batch_set_coeff_d2p": [P, F], "tiny_batch_set_uref": [P, F, C.c_int],
         "tiny_batch_group_solve": [C.POINTER(P), C.c_int, I],
@@ -407,6 +407,10 @@ class TinyBatchSolver:
         """0 = workgroups in index order, 1 = longest first by a predicted iteration count (register-resident row kernels), -1 (default) =
         automatic: longest first for a launch that starts from a reset workspace."""
         self._check(self.lib.tiny_batch_set_dispatch(self._h, mode))
+
+    def set_tile_queue(self, stride: int):
+        """tile16's tile queue under longest-first dispatch: -1 automatic, 0 one counter, k = every k-th wave takes tiles from the short end of the order."""
+        self._check(self.lib.tiny_batch_set_tile_queue(self._h, stride))
 
     def dispatch_applied(self) -> int:
         """0 index order, 1 predicted longest first, 2 the caller's order — what the most recent solve launch did."""

@@ -140,7 +140,7 @@ SCRATCH_PINS = {
     # traffic, which test_tile16_iteration_loop_is_free_of_scratch_traffic checks separately
     # <N, EXACT, COLD, MPC>; MPC = the closed loop on chip (round 4)
     # <N, EXACT, COLD, MPC, BR, XR>
-    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb1ELb1ELb0ELb0ELb0EEE"): 28,
+    ("admm_tile16.hip", "admm_tile16_kernelILi30ELb1ELb1ELb0ELb0ELb0EEE"): 32,   # (28 before the two-ended tile queue: one more scalar across the tile loop)
     ("admm_tile16.hip", "admm_tile16_kernelILi30ELb1ELb0ELb0ELb0ELb0EEE"): 188,
     ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb1ELb0ELb0ELb0EEE"): 0,
     ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb0ELb0ELb0ELb0EEE"): 0,
@@ -151,11 +151,11 @@ SCRATCH_PINS = {
     ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb1ELb1ELb0ELb0EEE"): 0,
     ("admm_tile16.hip", "admm_tile16_kernelILi30ELb0ELb0ELb1ELb0ELb0EEE"): 0,
     # the "pi" instantiations (BR: bounds, XR: reference through per-wave LDS-DMA slots; admm_tile16_pi.hip), exact arithmetic, cold / warm start
-    ("admm_tile16_pi.hip", "admm_tile16_kernelILi30ELb1ELb1ELb0ELb1ELb1EEE"): 72,
+    ("admm_tile16_pi.hip", "admm_tile16_kernelILi30ELb1ELb1ELb0ELb1ELb1EEE"): 88,
     ("admm_tile16_pi.hip", "admm_tile16_kernelILi30ELb1ELb0ELb0ELb1ELb1EEE"): 200,
     ("admm_tile16_pi.hip", "admm_tile16_kernelILi30ELb1ELb1ELb0ELb1ELb0EEE"): 48,
     ("admm_tile16_pi.hip", "admm_tile16_kernelILi30ELb1ELb0ELb0ELb1ELb0EEE"): 188,
-    ("admm_tile16_pi.hip", "admm_tile16_kernelILi30ELb1ELb1ELb0ELb0ELb1EEE"): 44,
+    ("admm_tile16_pi.hip", "admm_tile16_kernelILi30ELb1ELb1ELb0ELb0ELb1EEE"): 48,
     ("admm_tile16_pi.hip", "admm_tile16_kernelILi30ELb1ELb0ELb0ELb0ELb1EEE"): 192,
     # the nx = 32 tile kernel keeps no state in registers (duals in LDS, slack streamed): nothing may spill
     # (round 4: <EXACT, TWO> — TWO is the instantiation for horizons whose duals leave room for a second workgroup per CU: it must also stay

@@ -1941,6 +1941,50 @@ def test_config4_full_size_properties(tinympc, oracle_mod, B):
     sol.close()
 
 
+def test_tile16_two_ended_tile_queue_solves_every_tile_exactly_once(tinympc, oracle_mod):
+    """tiny_batch_set_tile_queue: every k-th wave of admm_tile16.hip claims its tiles from the short end of the dispatch order (one atomic word, head
+    count in the low and tail count in the high half).  Whatever the stride — 1: every wave at the tail, 3: strides that do not divide the wave
+    count, 255: a single tail wave — and whatever the launch (fewer tiles than waves, ragged last tile, predicted order and index order,
+    shared tables and the per-instance-table instantiation) every instance must be solved exactly once: all work arrays, residuals, status and
+    iteration counts bit for bit those of the single counter, and of the oracle on a sample.  The automatic choice must switch it on for the
+    headline launch only (cold start, predicted order, >= 3 tiles per wave slot), which shows in nothing but the time."""
+    O, pr = oracle_mod, tinympc.problems
+    prob = pr.quadrotor(20, 30)
+    bnds = pr.bounds_arrays(prob)
+    for B, per_instance in ((1, False), (17, False), (1000, True), (5000, False), (20000, False), (49152 + 5, False), (49152 + 5, True)):
+        x0, table, start = pr.tracking_batch(B, 30, seed=B % 1000)
+        sol = tinympc.TinyBatchSolver(prob, B)
+        sol.select_kernel(2); sol.set_row_kernel(5); sol.set_dispatch(1)
+        if per_instance:   # every instance its own limits, constant along the horizon: the pi instantiation with resident rows
+            rng = np.random.default_rng(B)
+            scale = (1.0 + 0.2 * rng.random((B, 1, 1))).astype(np.float32)
+            sol.set_bounds(*[(b[None] * scale).astype(np.float32) for b in bnds])
+        else:
+            sol.set_bounds(*bnds)
+        sol.set_xref_window(table, start)
+        assert sol.kernel_name() == ("tile16<12,4,30,exact,pi>" if per_instance else "tile16<12,4,30,exact>"), sol.kernel_name()
+        ref = None
+        for stride in (0, 1, 3, 8, 255, -1):
+            sol.set_tile_queue(stride)
+            sol.reset_workspace(); sol.set_x0(x0)
+            rc = sol.solve()
+            got = sol.get_state()
+            assert (got["iter"] >= 1).all() and (got["status"] >= 0).all()
+            if ref is None:
+                ref, rc0 = got, rc
+                continue
+            assert rc == rc0
+            assert_bitwise(got, ref, f"tile queue stride {stride} vs one counter, B={B}, per-instance bounds {per_instance}")
+        if not per_instance:
+            idx = np.unique(np.concatenate([np.arange(min(B, 40)), np.arange(max(B - 40, 0), B)]))
+            st = O.new_state(len(idx), 12, 4, 30); st["x"][:, 0] = x0[idx]
+            O.Oracle(prob, np.float32, O.DEFAULT_SETTINGS).solve(st, *bnds, pr.expand_windows(table, start, 30)[idx], nthreads=8)
+            assert_bitwise({k: ref[k][idx] for k in STATE_ORDER + SCALARS}, st, f"tile queue, B={B} vs oracle")
+        sol.close()
+    with pytest.raises(Exception):
+        sol = tinympc.TinyBatchSolver(prob, 16); sol.set_tile_queue(256)
+
+
 @pytest.mark.parametrize("exact", [True, False])
 def test_tile16_kernel_equals_row_kernel_bitwise(tinympc, oracle_mod, exact):
     """admm_tile16.hip (16 instances per wavefront as MFMA columns, set_row_kernel(5)) against the 16-lane row kernel on the
