@@ -63,15 +63,16 @@ __global__ __launch_bounds__(TILES ? 4 * WAVE : WAVE) void dispatch_key_kernel(c
 // order[] = the n groups sorted by key, largest first: counting sort over 2 048 buckets = sign-less float bits >> 20 (exponent
 // and three mantissa bits; monotonic for the non-negative keys).  One workgroup; the order inside a bucket is arbitrary.
 constexpr int NBUCKET = 2048;
-__global__ __launch_bounds__(1024) void dispatch_order_kernel(const float *__restrict__ key, int *__restrict__ order, int n, int *__restrict__ counters)
+// one workgroup: order[] = 0 .. n-1 sorted by bucket, largest bucket first (counting sort; the order inside a bucket is arbitrary)
+template <class BucketOf>
+__device__ inline void bucket_sort_descending(BucketOf bucket_of, int *__restrict__ order, int n, int *__restrict__ counters)
 {
     __shared__ int cnt[NBUCKET], sa[NBUCKET], sb[NBUCKET];
     const int t = threadIdx.x;
     if (t == 0 && counters) counters[0] = counters[1] = 0; // the solve kernel's unsolved count and tile queue (saves the memset node in front of this launch)
-    auto bucket = [](float k) { return (int)((__builtin_bit_cast(unsigned, k) & 0x7fffffffu) >> 20); };
     for (int b = t; b < NBUCKET; b += 1024) cnt[b] = 0;
     __syncthreads();
-    for (int g = t; g < n; g += 1024) atomicAdd(&cnt[bucket(key[g])], 1);
+    for (int g = t; g < n; g += 1024) atomicAdd(&cnt[bucket_of(g)], 1);
     __syncthreads();
     // inclusive scan over the buckets in DESCENDING key order (index r = NBUCKET-1-b)
     for (int r = t; r < NBUCKET; r += 1024) sa[r] = cnt[NBUCKET - 1 - r];
@@ -90,7 +91,44 @@ __global__ __launch_bounds__(1024) void dispatch_order_kernel(const float *__res
         dst[b] = src[r] - cnt[b]; // dst is free now
     }
     __syncthreads();
-    for (int g = t; g < n; g += 1024) order[atomicAdd(&dst[bucket(key[g])], 1)] = g;
+    for (int g = t; g < n; g += 1024) order[atomicAdd(&dst[bucket_of(g)], 1)] = g;
+}
+
+__global__ __launch_bounds__(1024) void dispatch_order_kernel(const float *__restrict__ key, int *__restrict__ order, int n, int *__restrict__ counters)
+{
+    bucket_sort_descending([key](int g) { return (int)((__builtin_bit_cast(unsigned, key[g]) & 0x7fffffffu) >> 20); }, order, n, counters);
+}
+
+// Warm-started launches (round 4, second session).  The predictor above is blind there — one sweep from a warm workspace sees residuals of the
+// size of the tolerance — but the instance's own PAST is not: iteration counts of consecutive MPC steps are strongly correlated (an instance at
+// its bounds stays there for a while).  Key of a unit (a group of 4 instances, a tile of 16) = the largest iteration count the previous solve
+// spent on one of its instances, read from the workspace's iter array; the bucket is the count itself.  Replayed on the true counts of the
+// tracking loop (tests/fuzz/sim_history_dispatch.py): makespan of a warm-started step of 65 536 instances 108 -> 78 iterations on the
+// 16-instances-per-wave kernel (order by the TRUE counts: 77.5), 148 -> 120 on the 16-lane kernel.
+// use_sum: the key of a unit is the SUM of its instances' counts instead of the largest — the better predictor of a tile's TOTAL over the steps of an
+// on-chip closed-loop run (makespan 1 262 against 1 298 iterations; the previous run's own total, which only the kernel could record, 1 236), the
+// worse one of its next single solve (79.7 against 78.2) and for groups of four (2 244 against 2 175)
+__global__ __launch_bounds__(1024) void dispatch_order_history_kernel(const int *__restrict__ iter, int unit, int batch, int use_sum, int *__restrict__ order, int n,
+                                                                      int *__restrict__ counters)
+{
+    bucket_sort_descending(
+        [=](int g) {
+            int m = 0;
+            for (int k = 0; k < unit; k++)
+            {
+                const int i = g * unit + k;
+                if (i < batch) m = use_sum ? m + max(iter[i], 0) : max(m, iter[i]);
+            }
+            return min(max(m, 0), NBUCKET - 1);
+        },
+        order, n, counters);
+}
+
+hipError_t launch_dispatch_order_history(const int *iter, int batch, int unit, int *order, int *counters, hipStream_t stream, int use_sum)
+{
+    const int n = (batch + unit - 1) / unit;
+    hipLaunchKernelGGL(dispatch_order_history_kernel, dim3(1), dim3(1024), 0, stream, iter, unit, batch, use_sum, order, n, counters);
+    return hipGetLastError();
 }
 
 // tile != 0: order[] is a permutation of the ceil(batch/16) tiles of the 16-instances-per-wave kernel

@@ -415,7 +415,8 @@ struct TinyBatch
     bool x0_zero_pending = false; // reset_workspace(): x.col(0) and x0buf read as zero until a set_x0 overwrites them
     int variant = VAR_AUTO;
     int row_family_forced = -1; // tiny_batch_set_row_kernel
-    int last_dispatch = 0;        // what the most recent solve launch did: 0 index order, 1 predicted longest first, 2 the caller's order
+    int last_dispatch = 0;        // what the most recent solve launch did: 0 index order, 1 predicted longest first, 2 the caller's order, 3 longest first by the previous solve's counts
+    bool iter_history = false;    // iter[] holds the counts of a solve of THIS workspace's instances (not a reset, not an upload): the history order's key
     bool closed_loop_run = false; // inside tiny_batch_mpc_run_*(steps > 1): the auto choice keeps the kernel with the on-chip loop
     bool h16 = false; // ROW-layout arrays, Xref and bounds stored as IEEE binary16 (tiny_batch_set_storage)
     bool dual32 = false; // with h16: the duals pair gy IS fp32 right now (the state of the array)
@@ -629,7 +630,15 @@ int store_input(TinyBatch *tb, InputArr &in, const float *host, bool shared, int
 
 // tiny_batch_set_dispatch(-1), the default: the predictor sweep and the sort pay where the iteration counts of a launch spread widely — a launch that starts from a
 // reset workspace (65 536 tracking instances, wall time per solve: 2.20 -> 1.76 ms; 16 384: 0.82 -> 0.68) — and cost 2 - 4 % on warm-started steps (1.62 -> 1.66 ms)
-int dispatch_effective(const TinyBatch *tb) { return tb->dispatch_mode >= 0 ? tb->dispatch_mode : (tb->cold_pending ? 1 : 0); }
+// (second session of round 4) ... and a warm-started launch is ordered by what the predictor cannot see and the workspace already holds: the iteration counts of the
+// PREVIOUS solve of the same instances (dispatch_order.hip, history order; mode 2): consecutive MPC steps are strongly correlated.  65 536 tracking instances,
+// warm-started step: makespan 108 -> 78 iterations on the true counts (tests/fuzz/sim_history_dispatch.py).
+int dispatch_effective(const TinyBatch *tb)
+{
+    if (tb->dispatch_mode == 2) return tb->iter_history && !tb->cold_pending ? 2 : 0;
+    if (tb->dispatch_mode >= 0) return tb->dispatch_mode;
+    return tb->cold_pending ? 1 : (tb->iter_history ? 2 : 0);
+}
 
 bool bounds_all_shared(const TinyBatch *tb)
 {
@@ -904,10 +913,12 @@ int row_family(const TinyBatch *tb);
 constexpr int kTile16AutoPerCu = 160;
 int dispatch_effective(const TinyBatch *tb);
 bool tile16_auto_size(const TinyBatch *tb) { return dispatch_effective(tb) == 1 && tb->batch >= kTile16AutoPerCu * tb->n_cu; }
-// ... and for a closed-loop run (tiny_batch_mpc_run_async: all MPC steps of a tile inside one launch, index order): since the live-out rows are transposed in
-// registers the MPC instantiation keeps 1 scratch access per iteration instead of 15, and the warm-started tracking loop measures, ms per MPC step, tile16 / 16-lane
-// kernel: 32 768: 0.62 / 0.59, 49 152: 0.84 / 0.80, 65 536: 0.96 / 1.02, 98 304: 1.33 / 1.49, 131 072: 1.73 / 1.95 — from 240 instances per CU on
-constexpr int kTile16ClosedLoopPerCu = 240;
+// ... and for a closed-loop run (tiny_batch_mpc_run_async: all MPC steps of a tile inside one launch).  Since the tiles of a run are dispatched by the iteration
+// counts of the solve before it (history order, dispatch_order.hip: a tile's total over the steps of a run spreads widely, and four tiles per wave slot in index
+// order ended a third above even slots) the warm-started tracking loop measures, ms per MPC step of the second of two 20-step runs, tile16 / 16-lane kernel:
+// 24 576: 0.45 / 0.41, 32 768: 0.53 / 0.52, 40 960: 0.59 / 0.65, 49 152: 0.64 / 0.76, 65 536: 0.84 / 0.94, 98 304: 1.13 / 1.38, 131 072: 1.51 / 1.83 — from 160
+// instances per CU on (tools/closed_loop_threshold.py; in index order the cross-over was 240: 65 536: 0.96 / 1.02)
+constexpr int kTile16ClosedLoopPerCu = 160;
 bool tile16_closed_loop_size(const TinyBatch *tb) { return tb->batch >= kTile16ClosedLoopPerCu * tb->n_cu; }
 
 // fp16 storage: bring the duals pair to the width the coming launch implements.  Under tiny_batch_set_storage(tb, 16) fp32 duals are a
@@ -1194,7 +1205,7 @@ int prepare_solve(TinyBatch *tb, int *variant)
     int v = 0;
     TRY(resolve_variant(tb, &v));
     if (tb->gains_dirty) TRY(pack_gains(tb));
-    if (dispatch_effective(tb) == 1 && !tb->order_buf)
+    if (dispatch_effective(tb) != 0 && !tb->order_buf)
     {
         TRY(dev_alloc_zero(&tb->key_buf, (size_t)tb->bpad4 / 4 + (size_t)tb->bpad4 / 16 + 16)); // group keys, then tile keys
         TRY(dev_alloc_zero((float **)&tb->order_buf, (size_t)tb->bpad4 / 4));
@@ -1228,7 +1239,14 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
     const bool predicted_order = layout == LAYOUT_ROW && dispatch_effective(tb) == 1 && !tb->order_dev && (fam_l == 0 || fam_l == 1 || fam_l == 5) && !tb->dual32 &&
                                  tb->bpad4 / 4 >= kDispatchMinGroups && tb->max_iter > 1;
     // [0] unsolved count, [1] tile queue of admm_tile16.hip: zeroed by the sort kernel of the predicted order where that runs (one stream node less)
-    if (!predicted_order) HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, 2 * sizeof(int), tb->stream));
+    const bool history_order = layout == LAYOUT_ROW && dispatch_effective(tb) == 2 && !tb->order_dev && (fam_l == 0 || fam_l == 1 || fam_l == 5) &&
+                               tb->bpad4 / 4 >= kDispatchMinGroups && tb->max_iter > 1;
+    if (history_order)
+    {
+        hipError_t ek = launch_dispatch_order_history(tb->iter, tb->batch, fam_l == 5 ? 16 : 4, tb->order_buf, tb->n_unsolved, tb->stream);
+        if (ek != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(ek));
+    }
+    else if (!predicted_order) HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, 2 * sizeof(int), tb->stream));
     if (predicted_order)
     {
         RowParams K;
@@ -1266,10 +1284,10 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
     {
         RowParams P;
         fill_row_params(tb, P, v == VAR_ROW_EXACT);
-        if (predicted_order) P.order = tb->order_buf;
+        if (predicted_order || history_order) P.order = tb->order_buf;
         const int fam = row_family(tb);
-        if (fam == 5 && !predicted_order) P.order = nullptr; // a caller's order lists groups of four instances, not tiles of sixteen
-        tb->last_dispatch = predicted_order ? 1 : (P.order ? 2 : 0);
+        if (fam == 5 && !predicted_order && !history_order) P.order = nullptr; // a caller's order lists groups of four instances, not tiles of sixteen
+        tb->last_dispatch = predicted_order ? 1 : history_order ? 3 : (P.order ? 2 : 0);
         if (P.dual32 && fam != 0 && fam != 4)
             return fail(TINY_BATCH_EUNSUPPORTED, "fp16 storage with fp32 duals runs on the register-resident 16-lane and quad kernels only "
                                                  "(batch-shared bounds, no optional terms, no forced row kernel)");
@@ -1290,6 +1308,7 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
         tb->ev_valid = true;
     }
     if (tb->max_iter > 0) tb->duals_zero_pending = tb->cold_pending = false; // consumed by the kernel's first iteration
+    if (tb->max_iter > 0) tb->iter_history = true;                            // iter[] now holds this launch's counts
     return 0;
 }
 
@@ -1509,7 +1528,7 @@ int tiny_batch_set_uref(TinyBatch *tb, const float *uref, int shared)
 int tiny_batch_set_dispatch(TinyBatch *tb, int mode)
 {
     CHECK_TB(tb);
-    if (mode < -1 || mode > 1) return fail(TINY_BATCH_EINVAL, "tiny_batch_set_dispatch: mode must be 0 (index order), 1 (longest first, predicted) or -1 (automatic)");
+    if (mode < -1 || mode > 2) return fail(TINY_BATCH_EINVAL, "tiny_batch_set_dispatch: mode must be 0 (index order), 1 (longest first, predicted), 2 (longest first by the previous solve's iteration counts) or -1 (automatic)");
     tb->dispatch_mode = mode;
     invalidate_graph(tb);
     return 0;
@@ -1783,7 +1802,7 @@ int tiny_batch_set_status(TinyBatch *tb, const int *iter, const int *status, con
     CHECK_TB(tb);
     TRY(set_device(tb));
     TRY(flush_pending(tb));
-    if (iter) HIP_TRY(hipMemcpyAsync(tb->iter, iter, (size_t)tb->batch * sizeof(int), hipMemcpyHostToDevice, tb->stream));
+    if (iter) { HIP_TRY(hipMemcpyAsync(tb->iter, iter, (size_t)tb->batch * sizeof(int), hipMemcpyHostToDevice, tb->stream)); tb->iter_history = false; }
     if (status) HIP_TRY(hipMemcpyAsync(tb->status, status, (size_t)tb->batch * sizeof(int), hipMemcpyHostToDevice, tb->stream));
     if (residuals) HIP_TRY(hipMemcpyAsync(tb->res, residuals, (size_t)tb->batch * 4 * sizeof(float), hipMemcpyHostToDevice, tb->stream));
     HIP_TRY(hipStreamSynchronize(tb->stream));
@@ -1821,6 +1840,7 @@ int tiny_batch_reset_workspace(TinyBatch *tb)
     tb->x0_zero_pending = true;
     tb->cold_pending = true;
     tb->duals_zero_pending = false;
+    tb->iter_history = false;
     return 0;
 }
 
@@ -1912,9 +1932,19 @@ int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, 
         RowParams P;
         fill_row_params(tb, P, v == VAR_ROW_EXACT);
         P.mpc_steps = steps; P.window_advance = window_advance; P.u0_traj = d_u0_traj;
-        if (fam == 5) P.order = nullptr; // a caller's order lists groups of four instances, not tiles (index order inside a closed-loop run)
-        tb->last_dispatch = P.order ? 2 : 0;
-        HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, 2 * sizeof(int), tb->stream)); // [0] unsolved count, [1] tile queue of admm_tile16.hip
+        if (fam == 5) P.order = nullptr; // a caller's order lists groups of four instances, not tiles
+        // the run's tiles / groups longest first by the counts of the solve before it (the last step of the previous run): a tile's total over the steps
+        // of a run spreads 150 ... 700 iterations around a mean of 280 (65 536 tracking instances, 20 steps) and four tiles per wave slot in index order end
+        // 33 % above even slots; ordered by the previous step's counts 15 % (tests/fuzz/sim_history_dispatch.py)
+        const bool history_order = dispatch_effective(tb) == 2 && !tb->order_dev && (fam == 0 || fam == 5) && tb->bpad4 / 4 >= kDispatchMinGroups && tb->order_buf;
+        if (history_order)
+        {
+            hipError_t ek = launch_dispatch_order_history(tb->iter, tb->batch, fam == 5 ? 16 : 4, tb->order_buf, tb->n_unsolved, tb->stream, fam == 5 /* a tile's total over the run: by the sum */);
+            if (ek != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(ek));
+            P.order = tb->order_buf;
+        }
+        else HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, 2 * sizeof(int), tb->stream)); // [0] unsolved count, [1] tile queue of admm_tile16.hip
+        tb->last_dispatch = history_order ? 3 : (P.order ? 2 : 0);
         hipError_t e = fam == 0   ? launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, false, P, tb->stream)
                        : fam == 5 ? launch_admm_tile16(tb->N, v == VAR_ROW_EXACT, P, tb->stream, tb->n_cu)
                                   : launch_admm_quadlane(tb->N, v == VAR_ROW_EXACT, false, P, tb->stream);
@@ -1922,6 +1952,7 @@ int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, 
         if (d_u0_traj) TRY(launch_unpack(tb, work_ptr(tb, TINY_ARR_U), d_u0_traj + (size_t)(steps - 1) * u0n, tb->layout, 1, tb->batch, 0, 1));
         TRY(enqueue_plant_step(tb, window_advance));
         tb->duals_zero_pending = tb->cold_pending = false;
+        tb->iter_history = true; // iter[] = the counts of the run's last solve
         tb->ev_valid = false;
         return 0;
     }
@@ -2169,6 +2200,7 @@ int tiny_batch_set_storage_ex(TinyBatch *tb, int bits, int dual_bits)
     HIP_TRY(hipMemsetAsync(tb->res, 0, (size_t)tb->batch * 4 * sizeof(float), tb->stream));
     HIP_TRY(hipMemsetAsync(tb->status, 0, (size_t)tb->batch * sizeof(int), tb->stream));
     HIP_TRY(hipMemsetAsync(tb->iter, 0, (size_t)tb->batch * sizeof(int), tb->stream));
+    tb->iter_history = false;
     HIP_TRY(hipMemsetAsync(tb->x0buf, 0, (size_t)tb->batch * tb->nx * sizeof(float), tb->stream));
     tb->cold_pending = tb->duals_zero_pending = tb->x0_zero_pending = false;
     tb->derived_dirty[0] = tb->derived_dirty[1] = true;

@@ -173,5 +173,7 @@ hipError_t launch_admm_generic(const SolveParams &P, const float *gains, int nxc
 // longest-first dispatch order of the instance groups for the register-resident row kernel (dispatch_order.hip);
 // P.mats must be the fma gains
 hipError_t launch_dispatch_order(int nx, int nu, bool h16, const RowParams &P, float *key, int *order, hipStream_t stream, int tile = 0);
+// order[] = the ceil(batch/unit) units (unit = 4: groups, 16: tiles) sorted by the largest iter[] of their instances, largest first; zeroes counters[0..1]
+hipError_t launch_dispatch_order_history(const int *iter, int batch, int unit, int *order, int *counters, hipStream_t stream, int use_sum = 0);
 
 } // namespace tinympc

@@ -404,8 +404,9 @@ class TinyBatchSolver:
         self._check(self.lib.tiny_batch_set_row_kernel(self._h, family))
 
     def set_dispatch(self, mode: int):
-        """0 = workgroups in index order, 1 = longest first by a predicted iteration count (register-resident row kernels), -1 (default) =
-        automatic: longest first for a launch that starts from a reset workspace."""
+        """0 = workgroups in index order, 1 = longest first by a predicted iteration count (register-resident row kernels), 2 = longest first by the
+        iteration counts of the previous solve of this workspace (warm-started launches), -1 (default) = automatic: 1 for a launch that starts from a
+        reset workspace, 2 for a warm-started one."""
         self._check(self.lib.tiny_batch_set_dispatch(self._h, mode))
 
     def set_tile_queue(self, stride: int):
@@ -413,7 +414,8 @@ class TinyBatchSolver:
         self._check(self.lib.tiny_batch_set_tile_queue(self._h, stride))
 
     def dispatch_applied(self) -> int:
-        """0 index order, 1 predicted longest first, 2 the caller's order — what the most recent solve launch did."""
+        """0 index order, 1 predicted longest first, 2 the caller's order, 3 longest first by the previous solve's iteration counts — what the most recent
+        solve launch did."""
         return self._check(self.lib.tiny_batch_dispatch_applied(self._h))
 
     def set_dispatch_order_device(self, d_order_ptr):

@@ -11,7 +11,7 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
   bounds on, quadrotor_tracking.cpp:75-80), bounds u in [-0.5,0.5], x in [-5,5].
 One "step" = one cold-start tiny_solve() of every instance of the batch: reset_workspace (folded into the solve),
 x0 from a device buffer, per-instance reference windows gathered on the device from the trajectory table, one
-kernel launch running all ADMM iterations with per-instance early exit — preceded, by default (--dispatch 1), by the
+kernel launch running all ADMM iterations with per-instance early exit — preceded, by default (the library's automatic dispatch; --dispatch), by the
 predictor sweep and bucket sort that let the launch start its longest instance groups first (tiny_batch_set_dispatch;
 part of the timed step, not of `roofline.kernel_ms`).  Inputs are resident in HBM before the timed region.  The batch shards embarrassingly across ranks (weak scaling: 65536 instances per GPU); there is no
 data-path collective — torch.distributed is used only for the barriers and the max-over-ranks of the time.
@@ -250,9 +250,11 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (tracking; default 65536) / in all (random32; default 16384)")
     ap.add_argument("--mode", choices=["early_exit", "fixed10"], default="early_exit")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto (exact row / wave kernel), 1 streaming, 2 row exact, 3 row fast")
-    ap.add_argument("--dispatch", type=int, choices=[0, 1], default=1,
+    ap.add_argument("--dispatch", type=int, choices=[-1, 0, 1, 2], default=-1,
                     help="workgroup dispatch order of the row kernel: 0 index order, 1 longest first by the predicted iteration count "
-                         "(tiny_batch_set_dispatch; the predictor sweep and the sort run inside the timed region)")
+                         "(tiny_batch_set_dispatch; the predictor sweep and the sort run inside the timed region), 2 longest first by the previous "
+                         "solve's iteration counts (warm-started launches), -1 the library's default: 1 for the cold-start step timed here, 2 for the "
+                         "warm-started launches of the closed_loop extra")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and with it the parity sample)")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the fixed10 / transfers legs and the warm-started closed-loop and pipelined-batches extras (profiling runs: "
                     "its launches of the same kernel would be averaged into the per-kernel statistics)")
@@ -379,7 +381,7 @@ def main():
     n_unsolved = sol.wait()
     # reported by the library for the launches just timed (tiny_batch_dispatch_applied), not re-derived here
     dispatch_used = {0: "index order", 1: "longest first by predicted iteration count (predictor sweep + sort inside the timed region)",
-                     2: "caller-supplied order"}[sol.dispatch_applied()]
+                     2: "caller-supplied order", 3: "longest first by the previous solve's iteration counts"}[sol.dispatch_applied()]
     iters, status, _ = sol.get_status()
     npar = min(B, 2048)
     gpu_u = sol.get_u()[:npar].copy() if (rank == 0 and world == 1 and not args.no_cpu) else None  # parity sample, before the extras touch the workspace
@@ -515,9 +517,11 @@ def main():
             itc, stc, _ = sol.get_status()
             closed = {"kernel": sol.closed_loop_kernel_name(), "mpc_steps": ksteps, "ms_per_mpc_step": dt_c / ksteps * 1e3, "solves_per_s": B * ksteps / dt_c,
                       "mean_iters_last_step": float(itc.mean()), "frac_converged_last_step": float(np.mean(stc == 1)),
-                      "note": "warm-started tracking loop on the device (tiny_batch_mpc_run_async: one launch, state on chip between solves), wall time"}
+                      "dispatch_applied": sol.dispatch_applied(),
+                      "note": "warm-started tracking loop on the device (tiny_batch_mpc_run_async: one launch, state on chip between solves; tiles dispatched longest first "
+                              "by the iteration counts of the solve before the run, dispatch_applied 3), wall time"}
             # the same loop forced onto the other of the two kernels whose MPC loop stays on chip (round 4), for the record: the automatic choice is the
-            # sixteen-instances-per-wave kernel from 240 instances per compute unit on (measured cross-over), the 16-lane kernel below
+            # sixteen-instances-per-wave kernel from 160 instances per compute unit on (measured cross-over), the 16-lane kernel below
             other = 1 if closed["kernel"].startswith("tile16") else 5
             for key, fam_k in (("on_headline_kernel", 5), ("on_16_lane_kernel", 1)):
                 if fam_k != other:

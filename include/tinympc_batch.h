@@ -192,7 +192,7 @@ extern "C"
      * "stream<3,1>", with ",h16" appended under fp16 storage). */
     const char *tiny_batch_kernel_name(TinyBatch *tb);
     /* ... and of the kernel a closed-loop run of several steps (tiny_batch_mpc_run_async) launches, which can differ: both the 16-lane kernel and the
-     * matrix-core kernel keep their MPC loop on chip; the automatic choice takes the latter from 240 instances per compute unit on (measured cross-over)
+     * matrix-core kernel keep their MPC loop on chip; the automatic choice takes the latter from 160 instances per compute unit on (measured cross-over)
      * with batch-shared bounds, the former below that and with per-instance tables. */
     const char *tiny_batch_closed_loop_kernel_name(TinyBatch *tb);
     /* Debug guard zones (the stand-in for a GPU address sanitizer, which this platform does not offer).
@@ -265,10 +265,16 @@ extern "C"
      * few rounds deep and iteration counts are uneven, so what starts last decides when the launch ends; results never depend on the order).
      * mode 0: index order.  mode 1: longest first by a predicted iteration count — one fma forward sweep over the first
      * four horizon steps from the current workspace gives the largest primal residual per group of four instances, a bucket sort orders the groups;
-     * applied to launches of at least 4096 groups, a no-op elsewhere.  mode -1 (default, round 4): automatic — mode 1 for a launch that starts
-     * from a reset workspace (where the iteration counts spread widely: 2.20 -> 1.76 ms per solve of 65 536 tracking instances), mode 0 for
-     * warm-started ones (where the sweep costs 2 - 4 % and gains nothing).  The automatic kernel choice takes the 16-instances-per-wave kernel only
-     * for launches that are dispatched longest first (from 160 instances per compute unit on: it loses to the 16-lane kernel in index order).  The 16-instances-per-wave kernel (tile16) orders its tiles of
+     * applied to launches of at least 4096 groups, a no-op elsewhere.  mode 2 (second session of round 4): longest first by the iteration counts the
+     * PREVIOUS solve of this workspace left in iter[] (the largest of a group's / tile's instances) — the order for warm-started launches, where the
+     * sweep of mode 1 sees nothing (residuals of the size of the tolerance) and consecutive MPC steps are strongly correlated; index order where no
+     * such history exists (after a reset, after an upload of iter[]).  It also orders the tiles / groups of an on-chip closed-loop run
+     * (tiny_batch_mpc_run_async) by the solve before the run.  65 536 tracking instances, ms per warm-started MPC step: 1.39 -> 1.22 step by step
+     * on the 16-lane kernel, 0.92 -> 0.81 inside the on-chip loop of the 16-instances-per-wave kernel (tools/warm_dispatch_ab.py).
+     * mode -1 (default, round 4): automatic — mode 1 for a launch that starts from a reset workspace (where the iteration counts spread widely:
+     * 2.20 -> 1.76 ms per solve of 65 536 tracking instances), mode 2 for warm-started ones.  The automatic kernel choice takes the
+     * 16-instances-per-wave kernel only for cold-start launches that are dispatched longest first (from 160 instances per compute unit on: it loses
+     * to the 16-lane kernel in index order) and for closed-loop runs of that size.  The 16-instances-per-wave kernel (tile16) orders its tiles of
      * sixteen instances by the largest key of their four groups. */
     int tiny_batch_set_dispatch(TinyBatch *tb, int mode);
     /* The tile queue of the 16-instances-per-wave kernel (tile16) under longest-first dispatch.  A launch of q tiles per wave slot ends in a partial
@@ -278,8 +284,9 @@ extern "C"
      * tests/fuzz/sim_tile_deque.py).  -1 (default): automatic — stride 8 for cold-start launches in predicted order of at least three tiles per
      * slot and at most 32 768 tiles, otherwise one counter; 0: one counter; 1 .. 255: that stride.  Results never depend on it. */
     int tiny_batch_set_tile_queue(TinyBatch *tb, int stride);
-    /* What the most recent solve launch actually did: 0 = index order (also when mode 1 did not apply: small launch, a kernel
-     * without dispatch order), 1 = longest first by the predicted iteration count, 2 = the caller's order. */
+    /* What the most recent solve launch actually did: 0 = index order (also when mode 1 / 2 did not apply: small launch, a kernel
+     * without dispatch order, no history), 1 = longest first by the predicted iteration count, 2 = the caller's order, 3 = longest first by the
+     * previous solve's iteration counts. */
     int tiny_batch_dispatch_applied(TinyBatch *tb);
     /* The caller's own order (e.g. from the iteration counts of the previous MPC step): d_order is a device array holding a
      * permutation of the ceil(batch/4) group indices, workgroup b solves instances 4*d_order[b] .. +3; it must stay valid

@@ -2831,10 +2831,57 @@ def test_tile16_persistent_queue_at_full_size_equals_row_kernel_bitwise(tinympc,
     assert res[5][0]["iter"].max() >= 30 and res[5][0]["iter"].min() < 20  # the batch really is uneven: waves take different numbers of tiles
 
 
+@pytest.mark.parametrize("family", [1, 5])
+def test_history_order_of_warm_started_launches(tinympc, family):
+    """tiny_batch_set_dispatch(2) / the automatic mode on a warm workspace: groups (16-lane kernel) or tiles (sixteen-instances-per-wave kernel) are
+    dispatched longest first by the iteration counts the PREVIOUS solve of the same workspace left in iter[] (dispatch_order.hip,
+    dispatch_order_history_kernel) — step by step, inside the on-chip closed loop, and with the two-ended tile queue forced on top.  Nothing but
+    the time may change: every array, the residuals, status, iteration counts, the u0 trajectory and x0 of a tracking loop must equal the
+    index-order run bit for bit; tiny_batch_dispatch_applied() reports 3 only where a history exists (not after a reset, not after an upload of
+    iter[], not for launches below 4 096 groups)."""
+    pr = tinympc.problems
+    prob = pr.quadrotor(20, 30)
+    B = 20000 + 7
+    x0, table, start = pr.tracking_batch(B, 30, seed=11)
+    outs = {}
+    for mode in (0, 2, -1):
+        sol = tinympc.TinyBatchSolver(prob, B)
+        sol.select_kernel(2); sol.set_row_kernel(family); sol.set_dispatch(mode)
+        if family == 5 and mode == 2:
+            sol.set_tile_queue(3)
+        sol.set_bounds(*pr.bounds_arrays(prob)); sol.set_xref_window(table, start); sol.set_x0(x0)
+        applied = []
+        sol.solve(); applied.append(sol.dispatch_applied())                       # cold: no history
+        for _ in range(3):
+            sol.mpc_step_async(1); sol.synchronize(); applied.append(sol.dispatch_applied())
+        a = sol.get_state(); xa = sol.get_x0()
+        traj = sol.mpc_run_traj(6, 1); applied.append(sol.dispatch_applied())       # the on-chip loop (state stays on chip between solves)
+        b = sol.get_state(); xb = sol.get_x0()
+        it = sol.get_status()[0]
+        sol.set_status(iter=it)                                                   # an upload is not a history
+        sol.mpc_step_async(1); sol.synchronize(); applied.append(sol.dispatch_applied())
+        sol.reset_workspace(); sol.set_x0(x0); sol.solve(); applied.append(sol.dispatch_applied())
+        outs[mode] = (a, xa, traj, b, xb, sol.get_state())
+        assert applied == {0: [0, 0, 0, 0, 0, 0, 0], 2: [0, 3, 3, 3, 3, 0, 0], -1: [1, 3, 3, 3, 3, 0, 1]}[mode], (mode, applied)
+        sol.close()
+    for mode in (2, -1):
+        for k in (0, 3, 5):
+            assert_bitwise(outs[mode][k], outs[0][k], f"history order (mode {mode}) vs index order, family {family}, state {k}")
+        for k in (1, 2, 4):
+            assert np.array_equal(outs[mode][k], outs[0][k]), (mode, k)
+    small = tinympc.TinyBatchSolver(prob, 4096)
+    small.select_kernel(2); small.set_row_kernel(1); small.set_dispatch(2)
+    small.set_bounds(*pr.bounds_arrays(prob)); small.set_xref_window(table, start[:4096]); small.set_x0(x0[:4096])
+    small.solve(); small.mpc_step_async(1); small.synchronize()
+    assert small.dispatch_applied() == 0
+    small.close()
+
+
 def test_automatic_dispatch_and_kernel_choice_follow_the_kind_of_launch(tinympc):
     """tiny_batch_set_dispatch(-1), the default since round 4: a launch that starts from a reset (or fresh) workspace is dispatched longest first —
     and, from 160 instances per compute unit on, goes to the sixteen-instances-per-wave kernel, which wins only in that order —; a warm-started
-    one keeps index order and the 16-lane kernel.  An explicit mode overrides both ways.  None of it changes a bit of the results."""
+    one keeps the 16-lane kernel and is dispatched longest first by the iteration counts of the solve before it (second session of round 4; index order
+    before).  An explicit mode overrides both ways.  None of it changes a bit of the results."""
     pr = tinympc.problems
     prob = pr.quadrotor(20, 30)
     B = 65536
@@ -2853,11 +2900,11 @@ def test_automatic_dispatch_and_kernel_choice_follow_the_kind_of_launch(tinympc)
         want_warm = "tile16<12,4,30,exact>" if mode == 1 else "rowlane<12,4,30,exact>"
         assert sol.kernel_name() == want_warm, (mode, sol.kernel_name())          # the next launch is warm-started
         sol.set_x0(x0 * np.float32(0.98)); sol.reset_dual_variables(); sol.solve()
-        assert sol.dispatch_applied() == (1 if mode == 1 else 0), (mode, sol.dispatch_applied())
+        assert sol.dispatch_applied() == {None: 3, 0: 0, 1: 1}[mode], (mode, sol.dispatch_applied())   # automatic: by the counts of the solve before it
         warm = sol.get_u()
         sol.reset_workspace()
         assert sol.kernel_name() == want_cold, (mode, sol.kernel_name())
-        # a closed-loop run (all MPC steps of a tile inside one launch) takes the sixteen-instances-per-wave kernel from 240 instances per compute unit on
+        # a closed-loop run (all MPC steps of a tile inside one launch) takes the sixteen-instances-per-wave kernel from 160 instances per compute unit on
         assert sol.closed_loop_kernel_name() == "tile16<12,4,30,exact>", sol.closed_loop_kernel_name()
         outs[mode] = (cold, warm, sol.get_status()[0])
         sol.close()
@@ -2870,7 +2917,7 @@ def test_automatic_dispatch_and_kernel_choice_follow_the_kind_of_launch(tinympc)
     with pytest.raises(tinympc.TinyBatchError):
         s2 = tinympc.TinyBatchSolver(prob, 8)
         try:
-            s2.set_dispatch(2)
+            s2.set_dispatch(3)
         finally:
             s2.close()
 
