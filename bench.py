@@ -352,6 +352,13 @@ def main():
     d_x0 = torch.from_numpy(np.ascontiguousarray(x0)).cuda()
     lib, h = sol.lib, sol._h
 
+    def cold_name():
+        """name of the kernel a COLD-START launch takes (what step() runs): the automatic choice differs for the warm-started launch that would follow a solve"""
+        sol.reset_workspace()
+        return sol.kernel_name()
+
+    kname = cold_name()
+
     def step():
         sol.reset_workspace()
         sol._check(lib.tiny_batch_set_x0_device(h, C.c_void_p(d_x0.data_ptr())))
@@ -420,6 +427,7 @@ def main():
     if rank == 0 and world == 1 and args.mode == "early_exit" and not args.no_closed_loop:   # (profiling runs skip it: the same kernel on another workload)
         try:
             sol.set_settings(**dict(settings, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=10))
+            k10 = cold_name()   # (before the steps: it resets the workspace)
             for _ in range(2):
                 step()
             sol.synchronize()
@@ -435,7 +443,7 @@ def main():
                 step()
                 ms_f.append(sol.last_solve_ms())
             it10, st10, _ = sol.get_status()
-            fixed10 = {"solves_per_s": B * nst / dt_f, "ms_per_step": dt_f / nst * 1e3, "kernel": sol.kernel_name(), "kernel_ms": float(np.mean(ms_f)),
+            fixed10 = {"solves_per_s": B * nst / dt_f, "ms_per_step": dt_f / nst * 1e3, "kernel": k10, "kernel_ms": float(np.mean(ms_f)),
                        "iterations": int(it10.max()), "f32_frac": cost.flops_of(it10, st10) / (float(np.mean(ms_f)) * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                        "note": "tolerances 0, max_iter 10 (SURVEY.md section 8(d) config 2/3 'fixed-iteration'), exact arithmetic, wall time of the steps"}
         except Exception as e:  # noqa: BLE001
@@ -463,8 +471,9 @@ def main():
             transfers = {"error": f"{type(e).__name__}: {e}"}
     # the opt-in fma-chain arithmetic of the same kernel, for reference (not the headline: see DESIGN.md §3)
     fast = None
-    if extras_ok and sol.kernel_name().startswith(("rowlane", "tile16")):
+    if extras_ok and kname.startswith(("rowlane", "tile16")):
         sol.select_kernel(3)
+        kfast = cold_name()   # (before the steps: it resets the workspace)
         for _ in range(2):
             step()
         ms = []
@@ -472,7 +481,7 @@ def main():
             step()
             ms.append(sol.last_solve_ms())
         itf, stf, _ = sol.get_status()
-        fast = dict(kernel=sol.kernel_name(), kernel_ms=float(np.mean(ms)), solves_per_s=B / (float(np.mean(ms)) * 1e-3),
+        fast = dict(kernel=kfast, kernel_ms=float(np.mean(ms)), solves_per_s=B / (float(np.mean(ms)) * 1e-3),
                     f32_frac=cost.flops_of(itf, stf) / (float(np.mean(ms)) * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                     mean_iters=float(itf.mean()), note="kernel time only; parity bar = the reference's own fp64/fp32 spread")
         if not args.no_cpu:
@@ -484,7 +493,7 @@ def main():
             fast["_u_fixed10"] = sol.get_u()[:npar].copy()
             sol.set_settings(**settings)
         sol.select_kernel(0)
-    elif rank == 0 and world == 1 and not args.kernel and args.config == "random32" and sol.kernel_name().startswith(("tile48", "waveres")):
+    elif rank == 0 and world == 1 and not args.kernel and args.config == "random32" and kname.startswith(("tile48", "waveres")):
         sol.select_kernel(3)   # the nx = 32 class: kernel time of the fma instantiation only (its parity bar is held by the GPU tests)
         step()
         ms = []
@@ -492,7 +501,7 @@ def main():
             step()
             ms.append(sol.last_solve_ms())
         itf, stf, _ = sol.get_status()
-        fast = dict(kernel=sol.kernel_name(), kernel_ms=float(np.mean(ms)), solves_per_s=B / (float(np.mean(ms)) * 1e-3),
+        fast = dict(kernel=cold_name(), kernel_ms=float(np.mean(ms)), solves_per_s=B / (float(np.mean(ms)) * 1e-3),
                     f32_frac=cost.flops_of(itf, stf) / (float(np.mean(ms)) * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
                     mean_iters=float(itf.mean()), note="kernel time only; parity bar = the reference's own fp64/fp32 spread (tests/test_parity_gpu.py::test_wave_kernel_fma_arithmetic)")
         sol.select_kernel(0)
@@ -557,7 +566,6 @@ def main():
                 s2 = T.TinyBatchSolver(prob, B, device=dev_index, settings=settings)
                 s2.set_bounds(*pr.bounds_arrays(prob))
                 s2.set_xref_window(table, gstart[lo:hi])
-                s2.set_dispatch(0)  # overlapping launches already fill the tail; the predictor sweep would only add work
                 s2.set_stream(strm.cuda_stream)
                 sols.append(s2)
 
@@ -625,9 +633,9 @@ def main():
         tf = ROOT / "profiles" / "hbm_traffic.json"
         if tf.exists():
             try:
-                ent = json.loads(tf.read_text()).get(f"{sol.kernel_name()}:{args.mode}:{B}")
+                ent = json.loads(tf.read_text()).get(f"{kname}:{args.mode}:{B}")
                 if isinstance(ent, dict):
-                    isa = kernel_isa_sha(sol.kernel_name())
+                    isa = kernel_isa_sha(kname)
                     if ent.get("isa_sha") is not None and ent.get("isa_sha") == isa:
                         traffic, traffic_note = ent["bytes"], (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated ({ent.get('profile')}); bound to the "
                                                                f"kernel's device code {isa}")
@@ -657,7 +665,7 @@ def main():
             except Exception:
                 pass
         per_step = np.asarray(kernel_ms[1:] if len(kernel_ms) > 1 else kernel_ms)
-        roof.update(kernel=sol.kernel_name(), kernel_ms=k_ms,
+        roof.update(kernel=kname, kernel_ms=k_ms,
                     kernel_ms_per_step={"min": float(per_step.min()), "median": float(np.median(per_step)), "max": float(per_step.max()),
                                         "n": int(per_step.size), "note": "hipEvent pair around the solve launch, one untimed step each"},
                     hbm_GBs=hbm_ach, hbm_frac=hbm_ach / PEAK_HBM_GBS,
@@ -674,7 +682,7 @@ def main():
                                    + (f"{args.mode} (tol 1e-3, max_iter 100)" if args.mode == "early_exit" else "fixed 10 iterations"),
                        "nx": NX, "nu": NU, "N": N, "instances_per_gpu": B, "instances_total": total, "parallelism": f"batch-shard x{world}",
                        "world_size_seen": world_seen, "backend": (backend if dist is not None else "none (single process)"),
-                       "kernel": sol.kernel_name(),
+                       "kernel": kname,
                        "dispatch": dispatch_used,
                        "mean_iters": agg["sum_iters"] / agg["n_instances"],
                        "max_iters": agg["max_iters"], "frac_converged": agg["n_converged"] / agg["n_instances"]},

@@ -130,8 +130,10 @@ while time.time() < t_end:
     if rng.random() < 0.2:   # a caller-supplied dispatch order (random permutation of the groups of four) or the predicted one
         d_order = dev_ints(rng.permutation((B + 3) // 4).astype(np.int32))
         sol.set_dispatch_order_device(d_order.value)
-    elif rng.random() < 0.1:
-        sol.set_dispatch(1)
+    elif rng.random() < 0.2:
+        sol.set_dispatch(int(rng.choice([1, 2])))   # predictor / history order (they act on launches of >= 4096 groups; smaller ones check the plumbing)
+    if rng.random() < 0.3:   # tile16's two-ended tile queue at a forced stride: applies to cold-start launches of any size
+        sol.set_tile_queue(int(rng.integers(0, 10)))
     orc = O.Oracle(prob, ("h16d" if h16d else "h16") if h16 else np.float32, settings)
     if opt[0]:
         orc.set_uref(R(uref))

@@ -6,7 +6,9 @@ few hundred tiles left over occupy a sixth of the chip for one more tile's lengt
 65 536 instances).  No order of ONE queue avoids that; letting every k-th wave draw from the SHORT end of the same order does: such a wave fits
 one tile more into the same time.  This script replays the oracle's TRUE iteration counts (tiles of sixteen in lock step, 1 024 one-wave-per-SIMD
 slots, 3.5 iterations of fixed cost per tile) for the predictor's order and several strides and batch sizes.  DESIGN.md 5.4 quotes its output;
-tools/t16_queue_ab.py is the measurement on the chip.      python tests/fuzz/sim_tile_deque.py [batch,seed ...]"""
+tools/t16_queue_ab.py is the measurement on the chip.      python tests/fuzz/sim_tile_deque.py [batch,seed ...]
+With the argument `regroup` instead: what INSTANCE-level regrouping into tiles could add on the headline batch (lock step 1.125) — by the true counts, by the
+predictor, and by the residuals after k real ADMM iterations of every instance (which no launch has for free)."""
 import sys, heapq, numpy as np
 sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[2]))
 import accelerated_tinympc_amd as T
@@ -42,7 +44,30 @@ def makespan(tiles_in_order, stride):
     return mk
 
 
-cases = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(65536, 1), (65536, 7), (40960, 3), (49152, 4), (81920, 9), (98304, 5), (131072, 6)]
+if sys.argv[1:] == ["regroup"]:
+    B = 65536
+    x0, table, start = pr.tracking_batch(B, N)
+    xr = pr.expand_windows(table, start, N)
+    def run(max_iter):
+        st = O.new_state(B, 12, 4, N); st["x"][:, 0] = x0
+        O.Oracle(prob, np.float32, dict(O.DEFAULT_SETTINGS, max_iter=max_iter)).solve(st, xmn, xmx, umn, umx, xr, nthreads=8)
+        return st
+    it = run(100)["iter"].astype(np.int64)
+    def report(name, k):
+        tiles = it[np.argsort(-k, kind="stable")].reshape(-1, 16).max(1)   # tiles of instances adjacent in the key's order, queued in that order
+        print(f"{name:44s} corr {np.corrcoef(k, it)[0, 1]:.3f}  lock step {tiles.mean() / it.mean():.3f}  one counter {makespan(tiles, 0):6.1f}  stride 8 {makespan(tiles, 8):6.1f}", flush=True)
+    report("TRUE counts", it.astype(np.float64))
+    x = x0.astype(np.float64); key = np.zeros(B)
+    for i in range(4):
+        u = -(x @ K.T)
+        key = np.maximum(key, np.max(np.abs(x - np.clip(x, -5, 5)), axis=1)); key = np.maximum(key, np.max(np.abs(u - np.clip(u, -0.5, 0.5)), axis=1))
+        x = x @ A.T + u @ Bm.T
+    report("predictor (4 steps of the LQR rollout)", key)
+    for k in (2, 4, 6, 10):
+        r = run(k)["residuals"].astype(np.float64)
+        report(f"largest residual after {k} iterations", r.max(axis=1))
+    sys.exit(0)
+cases = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(65536, 20241024), (65536, 7), (40960, 3), (49152, 4), (81920, 9), (98304, 5), (131072, 6)]
 for B, seed in cases:
     it, key = workload(B, seed)
     tile_true, tile_key = it.reshape(-1, 16).max(1), key.reshape(-1, 16).max(1)

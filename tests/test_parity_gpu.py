@@ -1405,8 +1405,8 @@ def test_kernel_selection_and_option_errors(tinympc):
     with pytest.raises(tinympc.TinyBatchError):
         q17.mpc_run_async(0, 0)
     with pytest.raises(tinympc.TinyBatchError):
-        q17.set_dispatch(2)
-    q17.set_dispatch(1)                                            # accepted everywhere, acts on large rowlane launches only
+        q17.set_dispatch(3)
+    q17.set_dispatch(1); q17.set_dispatch(2)                                            # accepted everywhere, acts on large rowlane launches only
     q17.close()
     q40 = tinympc.TinyBatchSolver(pr.quadrotor(20, 70), 8)         # N > 64: only the streaming row kernel
     assert q40.kernel_name().startswith("rowstream")
