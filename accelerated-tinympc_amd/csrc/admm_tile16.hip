@@ -1170,7 +1170,12 @@ static inline unsigned t16_tail_stride(const RowParams &P, int ntiles, int nbloc
     if (ntiles > 32768) return 0u; // head and tail counts overshoot by at most one failed claim per wave
     if (forced >= 0) return (P.cold_start && P.mpc_steps <= 1) ? (unsigned)(forced > 255 ? 255 : forced) : 0u;
     if (!P.order || P.mpc_steps > 1 || !P.cold_start) return 0u; // (the kernel's cold-start instantiations carry the two-ended queue)
-    return ntiles >= 3 * nblocks * TILE16_WAVES ? 8u : 0u;
+    // how many waves: with q = tiles per slot, same-box A/B of strides 4 / 6 / 8 / 12 (tools/t16_queue_ab.py, kernel ms, two passes each): q = 3: 1.192 / 1.193 / 1.185 / 1.179,
+    // q = 4: 1.488 / 1.494 / 1.505 / 1.520 (one counter 1.600), q = 5: 1.808 / 1.831 / 1.858 / 1.854 (1.918); the replay says the same (q = 5: 151.0 against 152.5
+    // iterations; q = 8: 240 against 238): every 4th wave for 4 <= q < 8, every 8th otherwise
+    const int slots = nblocks * TILE16_WAVES;
+    if (ntiles < 3 * slots) return 0u;
+    return (ntiles >= 4 * slots && ntiles < 8 * slots) ? 4u : 8u;
 }
 
 #ifdef TINY_T16_PI_UNIT

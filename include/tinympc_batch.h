@@ -281,8 +281,8 @@ extern "C"
      * round: the slots return from their q-th tile together and the few tiles left occupy a fraction of the chip for one more tile's length.  With
      * stride k every k-th wave takes its tiles from the SHORT end of the predicted order instead of the long one, fits one tile more into the same
      * time, and the partial round disappears (65 536 tracking instances: makespan 132.5 -> 123 iterations simulated on the true counts,
-     * tests/fuzz/sim_tile_deque.py).  -1 (default): automatic — stride 8 for cold-start launches in predicted order of at least three tiles per
-     * slot and at most 32 768 tiles, otherwise one counter; 0: one counter; 1 .. 255: that stride.  Results never depend on it. */
+     * tests/fuzz/sim_tile_deque.py).  -1 (default): automatic — for cold-start launches in predicted order of at least three tiles per slot and at most 32 768 tiles stride 4
+     * (four to eight tiles per slot: the headline's 65 536 instances) or 8, otherwise one counter; 0: one counter; 1 .. 255: that stride.  Results never depend on it. */
     int tiny_batch_set_tile_queue(TinyBatch *tb, int stride);
     /* What the most recent solve launch actually did: 0 = index order (also when mode 1 / 2 did not apply: small launch, a kernel
      * without dispatch order, no history), 1 = longest first by the predicted iteration count, 2 = the caller's order, 3 = longest first by the
