@@ -2869,6 +2869,20 @@ def test_history_order_of_warm_started_launches(tinympc, family):
             assert_bitwise(outs[mode][k], outs[0][k], f"history order (mode {mode}) vs index order, family {family}, state {k}")
         for k in (1, 2, 4):
             assert np.array_equal(outs[mode][k], outs[0][k]), (mode, k)
+    if family == 1:   # fp16 storage (fp32 duals by preference): the history key reads iter[] only, so the order applies there too — same bits as index order
+        res = {}
+        for mode in (0, 2):
+            sol = tinympc.TinyBatchSolver(prob, B)
+            sol.select_kernel(2); sol.set_row_kernel(1); sol.set_storage(16); sol.set_dispatch(mode)
+            sol.set_bounds(*pr.bounds_arrays(prob)); sol.set_xref_window(table, start); sol.set_x0(x0)
+            sol.solve()
+            for _ in range(2):
+                sol.mpc_step_async(1)
+            sol.synchronize()
+            assert sol.dispatch_applied() == (3 if mode == 2 else 0), (mode, sol.dispatch_applied(), sol.kernel_name())
+            res[mode] = sol.get_state()
+            sol.close()
+        assert_bitwise(res[2], res[0], "history order vs index order under fp16 storage")
     small = tinympc.TinyBatchSolver(prob, 4096)
     small.select_kernel(2); small.set_row_kernel(1); small.set_dispatch(2)
     small.set_bounds(*pr.bounds_arrays(prob)); small.set_xref_window(table, start[:4096]); small.set_x0(x0[:4096])
