@@ -8,7 +8,7 @@ python -c "import __graft_entry__ as g; g.build()"
 python -m pytest tests/ -x -q -m "not gpu"
 /usr/local/graft/bin/gpurun --timeout 1200 -- "timeout -k 10 900 python -m pytest tests/ -x -q -m gpu > gpurun_out/checks_gputest.log 2>&1; tail -2 gpurun_out/checks_gputest.log; \
   timeout -k 10 200 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -1"
-/usr/local/graft/bin/gpurun --timeout 1200 -- "for f in fuzz_parity fuzz_parity64 fuzz_api fuzz_mpc fuzz_native fuzz_fast_families fuzz_stream_consistency; do \
+/usr/local/graft/bin/gpurun --timeout 1200 -- "for f in fuzz_parity fuzz_parity64 fuzz_api fuzz_mpc fuzz_native fuzz_fast_families fuzz_stream_consistency fuzz_dispatch; do \
   timeout -k 10 $((FUZZ + 90)) python tests/fuzz/\$f.py $FUZZ 1 > gpurun_out/checks_\$f.log 2>&1; echo \"\$f: \$(tail -1 gpurun_out/checks_\$f.log | cut -c1-160)\"; done"
 /usr/local/graft/bin/gpurun --timeout 900 -- "timeout -k 10 400 python bench.py > gpurun_out/checks_bench.log 2>&1; tail -1 gpurun_out/checks_bench.log | cut -c1-400; \
   timeout -k 10 400 python bench.py --config random32 > gpurun_out/checks_bench_random32.log 2>&1; tail -1 gpurun_out/checks_bench_random32.log | cut -c1-300"
