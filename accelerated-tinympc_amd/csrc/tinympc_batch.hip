@@ -633,6 +633,7 @@ int store_input(TinyBatch *tb, InputArr &in, const float *host, bool shared, int
 // (second session of round 4) ... and a warm-started launch is ordered by what the predictor cannot see and the workspace already holds: the iteration counts of the
 // PREVIOUS solve of the same instances (dispatch_order.hip, history order; mode 2): consecutive MPC steps are strongly correlated.  65 536 tracking instances,
 // warm-started step: makespan 108 -> 78 iterations on the true counts (tests/fuzz/sim_history_dispatch.py).
+constexpr int kDispatchMinGroups = 4096; // two rounds of waves on 256 CUs x 4 SIMDs x 2 waves
 int dispatch_effective(const TinyBatch *tb)
 {
     if (tb->dispatch_mode == 2) return tb->iter_history && !tb->cold_pending ? 2 : 0;
@@ -1205,7 +1206,9 @@ int prepare_solve(TinyBatch *tb, int *variant)
     int v = 0;
     TRY(resolve_variant(tb, &v));
     if (tb->gains_dirty) TRY(pack_gains(tb));
-    if (dispatch_effective(tb) != 0 && !tb->order_buf)
+    // (whatever the mode says NOW: a launch sequence enqueued after one prepare_solve — the captured graph of tiny_batch_mpc_run_async — gains a history with its
+    //  first solve, and its second one is then dispatched by it)
+    if (!tb->order_buf && tb->bpad4 / 4 >= kDispatchMinGroups)
     {
         TRY(dev_alloc_zero(&tb->key_buf, (size_t)tb->bpad4 / 4 + (size_t)tb->bpad4 / 16 + 16)); // group keys, then tile keys
         TRY(dev_alloc_zero((float **)&tb->order_buf, (size_t)tb->bpad4 / 4));
@@ -1228,7 +1231,6 @@ int prepare_solve(TinyBatch *tb, int *variant)
 }
 
 // the stream operations of one solve: counter reset + kernel launch (capturable)
-constexpr int kDispatchMinGroups = 4096; // two rounds of waves on 256 CUs x 4 SIMDs x 2 waves
 
 int enqueue_solve(TinyBatch *tb, int v, bool record_events)
 {
@@ -1237,10 +1239,10 @@ int enqueue_solve(TinyBatch *tb, int v, bool record_events)
     // pays off only when the launch is several rounds of waves deep
     const int fam_l = layout == LAYOUT_ROW ? row_family(tb) : -1;
     const bool predicted_order = layout == LAYOUT_ROW && dispatch_effective(tb) == 1 && !tb->order_dev && (fam_l == 0 || fam_l == 1 || fam_l == 5) && !tb->dual32 &&
-                                 tb->bpad4 / 4 >= kDispatchMinGroups && tb->max_iter > 1;
+                                 tb->bpad4 / 4 >= kDispatchMinGroups && tb->max_iter > 1 && tb->order_buf;
     // [0] unsolved count, [1] tile queue of admm_tile16.hip: zeroed by the sort kernel of the predicted order where that runs (one stream node less)
     const bool history_order = layout == LAYOUT_ROW && dispatch_effective(tb) == 2 && !tb->order_dev && (fam_l == 0 || fam_l == 1 || fam_l == 5) &&
-                               tb->bpad4 / 4 >= kDispatchMinGroups && tb->max_iter > 1;
+                               tb->bpad4 / 4 >= kDispatchMinGroups && tb->max_iter > 1 && tb->order_buf;
     if (history_order)
     {
         hipError_t ek = launch_dispatch_order_history(tb->iter, tb->batch, fam_l == 5 ? 16 : 4, tb->order_buf, tb->n_unsolved, tb->stream);

@@ -2883,6 +2883,23 @@ def test_history_order_of_warm_started_launches(tinympc, family):
             res[mode] = sol.get_state()
             sol.close()
         assert_bitwise(res[2], res[0], "history order vs index order under fp16 storage")
+    if family == 1:   # a launch SEQUENCE enqueued after one preparation (the captured graph of mpc_run on the rolled-loop kernel): its first solve has no
+        # history (fresh handle, mode 2 -> index order), its later ones have — the order buffer must exist by then (it was allocated by mode at first)
+        p17 = pr.quadrotor(20, 17)
+        B17 = 16384 + 16
+        x17, t17, s17 = pr.tracking_batch(B17, 17, seed=3)
+        res = {}
+        for mode in (0, 2):
+            sol = tinympc.TinyBatchSolver(p17, B17)
+            sol.set_dispatch(mode)
+            sol.set_bounds(*pr.bounds_arrays(p17)); sol.set_xref_window(t17, s17); sol.set_x0(x17)
+            assert sol.kernel_name().startswith("rowloop"), sol.kernel_name()
+            traj = sol.mpc_run_traj(3, 1)
+            assert sol.dispatch_applied() == (3 if mode == 2 else 0), (mode, sol.dispatch_applied())
+            res[mode] = (traj, sol.get_state())
+            sol.close()
+        assert np.array_equal(res[0][0], res[2][0])
+        assert_bitwise(res[2][1], res[0][1], "graph-replayed closed loop, history order vs index order")
     small = tinympc.TinyBatchSolver(prob, 4096)
     small.select_kernel(2); small.set_row_kernel(1); small.set_dispatch(2)
     small.set_bounds(*pr.bounds_arrays(prob)); small.set_xref_window(table, start[:4096]); small.set_x0(x0[:4096])
