@@ -5,9 +5,9 @@
 The other drivers use small batches, where tiny_batch_set_dispatch is a no-op (it acts on launches of >= 4 096 groups).  Every round here draws a batch
 of 16 384 ... 70 000 quadrotor instances (N = 30), the 16-lane or the 16-instances-per-wave kernel, settings (iteration limits, termination stride,
 tolerances, bound switches), a dispatch mode (-1 automatic, 0 index, 1 predictor, 2 history), a tile-queue stride (-1 ... 9) and a chain of one cold and
-up to three warm-started solves (duals reset or kept, x0 moved, some through the on-chip closed loop), and requires all twelve work arrays, the
+up to three warm-started solves (duals reset or kept, x0 moved), in half the rounds followed by an on-chip closed-loop run of 2 ... 4 MPC steps, and requires all twelve work arrays, the
 residuals, status and iter after every solve to equal the ORACLE's bit for bit — whatever the order in which waves took their groups / tiles — and
-tiny_batch_dispatch_applied() to report the order the mode and the history imply."""
+tiny_batch_dispatch_applied() to report the order the mode and the history imply; the run's u0 trajectory, final iter / status / x0 must equal the oracle's loop."""
 import sys, time
 from pathlib import Path
 import numpy as np
@@ -63,6 +63,24 @@ while time.time() < t_end:
             if not same:
                 print(f"MISMATCH round {rounds} solve {k}: {name}; B {B} family {fam} mode {mode} stride {stride} settings {settings} kernel {sol.kernel_name()} applied {got_d}")
                 sys.exit(1)
+    if rng.random() < 0.5 and settings["max_iter"] > 0:   # ... and an on-chip closed-loop run from the state the chain left (tiny_batch_mpc_run_traj: K MPC steps in
+        K, adv = int(rng.integers(2, 5)), int(rng.integers(0, 2))   # one launch, its tiles / groups in history order) against the oracle's loop (quadrotor_tracking.cpp:93-118)
+        traj = sol.mpc_run_traj(K, adv)
+        d_run = sol.dispatch_applied()
+        x = st["x"][:, 0].copy(); ws = start.copy()
+        for k in range(K):
+            st["x"][:, 0] = x; st["y"][:] = 0; st["g"][:] = 0
+            idx = np.minimum(ws[:, None] + np.arange(N)[None], table.shape[0] - 1)
+            orc.solve(st, *bnds, np.ascontiguousarray(table[idx]), nthreads=8); solves += 1
+            if not np.array_equal(traj[k], st["u"][:, 0]):
+                print(f"MISMATCH round {rounds} on-chip run step {k}: u0; B {B} family {fam} mode {mode} stride {stride} settings {settings} kernel {sol.closed_loop_kernel_name()} applied {d_run}")
+                sys.exit(1)
+            x = orc.plant_step(x, st["u"][:, 0]); ws = ws + adv
+        it_g, st_g, _ = sol.get_status()
+        if not (np.array_equal(it_g, st["iter"]) and np.array_equal(st_g, st["status"]) and np.array_equal(sol.get_x0(), x)):
+            print(f"MISMATCH round {rounds} on-chip run: iter / status / x0 after {K} steps; B {B} family {fam} mode {mode} settings {settings}")
+            sys.exit(1)
+        seen[("run:" + sol.closed_loop_kernel_name(), d_run)] = seen.get(("run:" + sol.closed_loop_kernel_name(), d_run), 0) + 1
     sol.close()
     rounds += 1
 print(f"fuzz ok: {rounds} rounds, {solves} solves of 16 384 ... 70 000 instances, every bit equal to the oracle under every dispatch order; (kernel, order applied): "
