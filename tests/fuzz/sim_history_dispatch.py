@@ -13,7 +13,7 @@ import accelerated_tinympc_amd as T
 from oracle import oracle as O
 pr = T.problems
 prob = pr.quadrotor(20, 30); N = 30
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 65536
 x0, table, start = pr.tracking_batch(B, N)
 bnds = pr.bounds_arrays(prob)
 orc = O.Oracle(prob, np.float32, O.DEFAULT_SETTINGS)
@@ -26,6 +26,7 @@ for k in range(40):   # quadrotor_tracking.cpp:93-118: x0, duals reset, window s
     counts.append(st["iter"].astype(np.int64))
     x = orc.plant_step(x, st["u"][:, 0]); start = start + 1
 counts = np.array(counts, dtype=np.float64)   # [step][instance]
+if "--save" in sys.argv: np.save('/tmp/cl_iters.npy', counts.astype(np.int64))   # for tests/fuzz/sim_runahead.py
 print(f"mean iterations per solve, steps 20-39: {counts[20:].mean():.2f}")
 
 
