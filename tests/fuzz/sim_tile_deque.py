@@ -53,16 +53,22 @@ if sys.argv[1:] == ["regroup"]:
         O.Oracle(prob, np.float32, dict(O.DEFAULT_SETTINGS, max_iter=max_iter)).solve(st, xmn, xmx, umn, umx, xr, nthreads=8)
         return st
     it = run(100)["iter"].astype(np.int64)
-    def report(name, k):
-        tiles = it[np.argsort(-k, kind="stable")].reshape(-1, 16).max(1)   # tiles of instances adjacent in the key's order, queued in that order
-        print(f"{name:44s} corr {np.corrcoef(k, it)[0, 1]:.3f}  lock step {tiles.mean() / it.mean():.3f}  one counter {makespan(tiles, 0):6.1f}  stride 8 {makespan(tiles, 8):6.1f}", flush=True)
-    report("TRUE counts", it.astype(np.float64))
     x = x0.astype(np.float64); key = np.zeros(B)
     for i in range(4):
         u = -(x @ K.T)
         key = np.maximum(key, np.max(np.abs(x - np.clip(x, -5, 5)), axis=1)); key = np.maximum(key, np.max(np.abs(u - np.clip(u, -0.5, 0.5)), axis=1))
         x = x @ A.T + u @ Bm.T
+    def report(name, k):
+        perm = np.argsort(-k, kind="stable")                     # tiles of instances adjacent in the key's order ...
+        tiles = it[perm].reshape(-1, 16).max(1)
+        q_own = tiles[np.argsort(-k[perm].reshape(-1, 16).max(1), kind="stable")]    # ... queued by that key
+        q_pred = tiles[np.argsort(-key[perm].reshape(-1, 16).max(1), kind="stable")]  # ... queued by the library's predictor (what a caller's batch order gets)
+        print(f"{name:60s} corr {np.corrcoef(k, it)[0, 1]:6.3f}  lock step {tiles.mean() / it.mean():.3f}  queued by the key itself: one counter {makespan(q_own, 0):6.1f} stride 4 {makespan(q_own, 4):6.1f}"
+              f"   by the predictor: {makespan(q_pred, 0):6.1f} / {makespan(q_pred, 4):6.1f}", flush=True)
+    report("index order (the batch as it is)", -np.arange(B, dtype=np.float64))
+    report("TRUE counts", it.astype(np.float64))
     report("predictor (4 steps of the LQR rollout)", key)
+    report("window start of the reference (what a caller could sort by)", -start.astype(np.float64))
     for k in (2, 4, 6, 10):
         r = run(k)["residuals"].astype(np.float64)
         report(f"largest residual after {k} iterations", r.max(axis=1))
