@@ -238,7 +238,7 @@ def test_native_names_header_is_plain_c_and_matches_the_binding(tinympc, tmp_pat
 
 @pytest.mark.parametrize("name", ["r01_bench_default_line.json", "r02_bench_default_line_d.json", "r02_bench_random32_line_b.json",
                                   "r04_bench_default_line_a.json", "r04_bench_random32_line_a.json", "r04_bench_default_line_b.json", "r04_bench_random32_line_b.json", "r04_bench_default_line_c.json", "r04_bench_random32_line_c.json",
-                                  "r04_bench_default_line_d.json", "r04_bench_random32_line_d.json"])
+                                  "r04_bench_default_line_d.json", "r04_bench_random32_line_d.json", "r04_bench_default_line_e.json"])
 def test_recorded_bench_line_has_the_contract_fields(name):
     """profiles/*_bench_*_line*.json are the stdout of `python bench.py [--config random32]` on the MI355X: the keys the driver reads."""
     import json
