@@ -154,18 +154,15 @@ __device__ __forceinline__ float get_elem(const float *src, long long i, int h16
 // of instances [0, nb).  Rows/instances beyond the source are left untouched (they were zeroed at allocation).
 // `mirror` (may be NULL): a plain copy of src, element for element — set_x0_device fills x.col(0) and the [B][nx] state buffer of the closed loop in
 // ONE launch (round 4: it was a device-to-device copy plus this kernel)
-// (IDX: the element counter's type — 32-bit where the array has fewer than 2^31 elements: the two 64-bit divisions per element were most of the 9.7 us this
-//  kernel took to pack the 786 432 floats of the headline batch's x0, second session of round 4)
-template <typename IDX>
 __global__ void pack_kernel(const float *__restrict__ src, float *__restrict__ dst, int layout, Geo g, int fam, int nb,
                             int shared, int step0, int nsteps, int h16, float *__restrict__ mirror = nullptr)
 {
     const int dim = fam ? g.nu : g.nx;
-    const IDX total = (IDX)nb * nsteps * dim;
-    for (IDX e = (IDX)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (IDX)gridDim.x * blockDim.x)
+    const long long total = (long long)nb * nsteps * dim;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x)
     {
         const int row = (int)(e % dim);
-        const IDX t = e / dim;
+        const long long t = e / dim;
         const int s = (int)(t % nsteps), b = (int)(t / nsteps);
         const float val = src[((long long)(shared ? 0 : b) * nsteps + s) * dim + row];
         put_elem(dst, idx_of(layout, g, fam, b, step0 + s, row), val, h16);
@@ -511,12 +508,8 @@ void free_layout(TinyBatch *tb, int layout)
 int launch_pack(TinyBatch *tb, const float *src, float *dst, int layout, int fam, int nb, bool shared, int step0, int nsteps, float *mirror = nullptr)
 {
     const long long total = (long long)nb * nsteps * (fam ? tb->nu : tb->nx);
-    if (total < (1ll << 31) - (1ll << 24)) // (room for the grid stride behind the last element)
-        hipLaunchKernelGGL(pack_kernel<unsigned>, dim3(grid_for(total)), dim3(256), 0, tb->stream, src, dst, layout, geo(tb), fam, nb,
-                           shared ? 1 : 0, step0, nsteps, h16_at(tb, layout, dst), mirror);
-    else
-        hipLaunchKernelGGL(pack_kernel<long long>, dim3(grid_for(total)), dim3(256), 0, tb->stream, src, dst, layout, geo(tb), fam, nb,
-                           shared ? 1 : 0, step0, nsteps, h16_at(tb, layout, dst), mirror);
+    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(256), 0, tb->stream, src, dst, layout, geo(tb), fam, nb,
+                       shared ? 1 : 0, step0, nsteps, h16_at(tb, layout, dst), mirror);
     HIP_TRY(hipGetLastError());
     return 0;
 }
