@@ -1921,6 +1921,7 @@ int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, 
     if (tb->nx > 64) return fail(TINY_BATCH_EUNSUPPORTED, "mpc_run supports nx <= 64");
     if (tb->max_iter <= 0) return fail(TINY_BATCH_EINVAL, "tiny_batch_mpc_run_async needs max_iter > 0");
     TRY(set_device(tb));
+    const bool from_reset = tb->cold_pending; // (flush_pending materialises the zeros and clears the flag: the run's first solve is the cold one all the same)
     TRY(flush_pending(tb)); // every solve of the run starts from "duals reset, workspace warm"
     tb->duals_zero_pending = true;
     int v = 0;
@@ -1939,14 +1940,26 @@ int tiny_batch_mpc_run_traj_async(TinyBatch *tb, int steps, int window_advance, 
         // of a run spreads 150 ... 700 iterations around a mean of 280 (65 536 tracking instances, 20 steps) and four tiles per wave slot in index order end
         // 33 % above even slots; ordered by the previous step's counts 15 % (tests/fuzz/sim_history_dispatch.py)
         const bool history_order = dispatch_effective(tb) == 2 && !tb->order_dev && (fam == 0 || fam == 5) && tb->bpad4 / 4 >= kDispatchMinGroups && tb->order_buf;
+        // ... and a run that starts from a reset workspace by the predictor of its first, cold solve (which is also its longest: 22 iterations against 11): steps 0 - 19
+        // of the tracking loop, makespan 1 522 iterations in index order, 1 299 by the predictor (by the true first-step counts 1 291; 16-lane kernel 2 336 -> 2 175)
+        const bool predicted_order = (tb->dispatch_mode == 1 || (tb->dispatch_mode == -1 && from_reset)) && !history_order && !tb->order_dev && (fam == 0 || fam == 5) && !tb->dual32 && tb->bpad4 / 4 >= kDispatchMinGroups &&
+                                     tb->order_buf && tb->max_iter > 1;
         if (history_order)
         {
             hipError_t ek = launch_dispatch_order_history(tb->iter, tb->batch, fam == 5 ? 16 : 4, tb->order_buf, tb->n_unsolved, tb->stream, fam == 5 /* a tile's total over the run: by the sum */);
             if (ek != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(ek));
             P.order = tb->order_buf;
         }
+        else if (predicted_order)
+        {
+            RowParams K;
+            fill_row_params(tb, K, false); // fma gains
+            hipError_t ek = launch_dispatch_order(tb->nx, tb->nu, tb->h16, K, tb->key_buf, tb->order_buf, tb->stream, fam == 5); // (its sort zeroes the two counters)
+            if (ek != hipSuccess) return fail(TINY_BATCH_EHIP, "kernel launch failed: %s", hipGetErrorString(ek));
+            P.order = tb->order_buf;
+        }
         else HIP_TRY(hipMemsetAsync(tb->n_unsolved, 0, 2 * sizeof(int), tb->stream)); // [0] unsolved count, [1] tile queue of admm_tile16.hip
-        tb->last_dispatch = history_order ? 3 : (P.order ? 2 : 0);
+        tb->last_dispatch = history_order ? 3 : predicted_order ? 1 : (P.order ? 2 : 0);
         hipError_t e = fam == 0   ? launch_admm_rowlane(tb->nx, tb->nu, tb->N, v == VAR_ROW_EXACT, false, P, tb->stream)
                        : fam == 5 ? launch_admm_tile16(tb->N, v == VAR_ROW_EXACT, P, tb->stream, tb->n_cu)
                                   : launch_admm_quadlane(tb->N, v == VAR_ROW_EXACT, false, P, tb->stream);

@@ -269,7 +269,8 @@ extern "C"
      * PREVIOUS solve of this workspace left in iter[] (the largest of a group's / tile's instances) — the order for warm-started launches, where the
      * sweep of mode 1 sees nothing (residuals of the size of the tolerance) and consecutive MPC steps are strongly correlated; index order where no
      * such history exists (after a reset, after an upload of iter[]).  It also orders the tiles / groups of an on-chip closed-loop run
-     * (tiny_batch_mpc_run_async) by the solve before the run.  65 536 tracking instances, ms per warm-started MPC step: 1.39 -> 1.22 step by step
+     * (tiny_batch_mpc_run_async) by the solve before the run; a run that starts from a reset workspace is ordered by mode 1's predictor of its first,
+     * cold solve (0.96 -> 0.84 ms per MPC step of that first run, 65 536 instances).  65 536 tracking instances, ms per warm-started MPC step: 1.39 -> 1.22 step by step
      * on the 16-lane kernel, 0.92 -> 0.81 inside the on-chip loop of the 16-instances-per-wave kernel (tools/warm_dispatch_ab.py).
      * mode -1 (default, round 4): automatic — mode 1 for a launch that starts from a reset workspace (where the iteration counts spread widely:
      * 2.20 -> 1.76 ms per solve of 65 536 tracking instances), mode 2 for warm-started ones.  The automatic kernel choice takes the

@@ -2864,10 +2864,18 @@ def test_history_order_of_warm_started_launches(tinympc, family):
         outs[mode] = (a, xa, traj, b, xb, sol.get_state())
         assert applied == {0: [0, 0, 0, 0, 0, 0, 0], 2: [0, 3, 3, 3, 3, 0, 0], -1: [1, 3, 3, 3, 3, 0, 1]}[mode], (mode, applied)
         sol.close()
+        # an on-chip closed-loop run that starts from a reset workspace: its tiles / groups by the predictor of its first (cold, longest) solve
+        sol = tinympc.TinyBatchSolver(prob, B)
+        sol.select_kernel(2); sol.set_row_kernel(family); sol.set_dispatch(mode)
+        sol.set_bounds(*pr.bounds_arrays(prob)); sol.set_xref_window(table, start); sol.set_x0(x0)
+        first = sol.mpc_run_traj(4, 1)
+        assert sol.dispatch_applied() == {0: 0, 2: 0, -1: 1}[mode], (mode, sol.dispatch_applied())
+        outs[mode] = outs[mode] + (first, sol.get_state())
+        sol.close()
     for mode in (2, -1):
-        for k in (0, 3, 5):
+        for k in (0, 3, 5, 7):
             assert_bitwise(outs[mode][k], outs[0][k], f"history order (mode {mode}) vs index order, family {family}, state {k}")
-        for k in (1, 2, 4):
+        for k in (1, 2, 4, 6):
             assert np.array_equal(outs[mode][k], outs[0][k]), (mode, k)
     if family == 1:   # fp16 storage (fp32 duals by preference): the history key reads iter[] only, so the order applies there too — same bits as index order
         res = {}
