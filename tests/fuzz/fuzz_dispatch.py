@@ -41,7 +41,8 @@ while time.time() < t_end:
     st = O.new_state(B, 12, 4, N); st["x"][:, 0] = x0
     xr = pr.expand_windows(table, start, N)
     history = False
-    for k in range(int(rng.integers(1, 5))):
+    from_reset = rng.random() < 0.25   # no chain: the on-chip run below starts from the reset workspace (its tiles by the predictor of its first, cold solve)
+    for k in range(0 if from_reset else int(rng.integers(1, 5))):
         if k > 0:
             if rng.random() < 0.7:
                 st["y"][:] = 0; st["g"][:] = 0; sol.reset_dual_variables()
@@ -63,10 +64,12 @@ while time.time() < t_end:
             if not same:
                 print(f"MISMATCH round {rounds} solve {k}: {name}; B {B} family {fam} mode {mode} stride {stride} settings {settings} kernel {sol.kernel_name()} applied {got_d}")
                 sys.exit(1)
-    if rng.random() < 0.5 and settings["max_iter"] > 0:   # ... and an on-chip closed-loop run from the state the chain left (tiny_batch_mpc_run_traj: K MPC steps in
+    if (from_reset or rng.random() < 0.5) and settings["max_iter"] > 0:   # ... and an on-chip closed-loop run from the state the chain left (tiny_batch_mpc_run_traj: K MPC steps in
         K, adv = int(rng.integers(2, 5)), int(rng.integers(0, 2))   # one launch, its tiles / groups in history order) against the oracle's loop (quadrotor_tracking.cpp:93-118)
         traj = sol.mpc_run_traj(K, adv)
         d_run = sol.dispatch_applied()
+        if from_reset and (B + 3) // 4 >= 4096 and settings["max_iter"] > 1:
+            assert d_run == {0: 0, 1: 1, 2: 0, -1: 1}[mode], f"run from a reset workspace: dispatch applied {d_run}, mode {mode}"
         x = st["x"][:, 0].copy(); ws = start.copy()
         for k in range(K):
             st["x"][:, 0] = x; st["y"][:] = 0; st["g"][:] = 0
